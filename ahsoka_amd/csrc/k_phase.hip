@@ -1,0 +1,790 @@
+// k_phase.hip -- stages S4..S8 of the per-chain phasing path for gfx950:
+// a persistent grid of workgroups, each pulling whole bubble chains from a
+// queue and running, for one chain at a time,
+//
+//   S4  read-pair similarity      (ReadScoring::scoreReadsetLocal,  :308-311)
+//   S5  cluster editing           (ClusterEditingSolver::run,       :312-314)
+//   S6  coverage / top clusters / consensus      (:346-404, helpers :550-779)
+//   S7  haplotype threading DP    (HaploThreader::computePaths,     :320,408)
+//   S8  haplotype -> consensus allele                               (:415-424)
+//
+// (line numbers: src/alignmentstoreadset.cpp of the reference).
+//
+// Data layout: reads are bit-planes over the chain's covered positions
+// (cover word + allele planes, word-major so lanes = reads load coalesced);
+// overlap and Hamming distance of a pair are popcounts.  The similarity
+// matrix W (int32, Q15.16) and the induced costs IC (2 x int64 per pair) are
+// dense n x n, symmetric, in this workgroup's slot of HBM; every access
+// pattern below is "one row, consecutive lanes = consecutive columns".  The
+// per-row maxima that drive the heuristic's edge choice live in LDS as packed
+// 64-bit (value, column) keys so that a row update is one ds_max_u64.
+//
+// All induced-cost arithmetic is exact integer arithmetic, so the result does
+// not depend on the order in which lanes apply updates; that is what lets one
+// outer iteration (one merge or one separation of two cliques, with all its
+// implied edges) be applied by 256 lanes at once and still equal the oracle's
+// edge-by-edge sequential loop bit for bit.
+#include <hip/hip_runtime.h>
+
+#include "detmath.h"
+#include "gnusort.h"
+#include "phase_kernels.h"
+#include "../../include/ahsoka_phase.h"
+
+namespace ahk {
+
+constexpr long long BIGV = 1ll << 40;
+constexpr int ROLE_NONE = 0, ROLE_A = 1, ROLE_B = 2, ROLE_FA = 3, ROLE_FB = 4;
+
+__device__ __forceinline__ long long wval(int w) {
+  return w == W_PERM ? BIGV : (w == W_FORB ? -BIGV : (long long)w);
+}
+__device__ __forceinline__ long long icf_term(long long p, long long q) {
+  return (p > 0 && q > 0) ? (p < q ? p : q) : 0;
+}
+__device__ __forceinline__ long long icp_term(long long p, long long q) {
+  if (p < 0 && q > 0) return q < -p ? q : -p;
+  if (p > 0 && q < 0) return -q < p ? -q : p;
+  return 0;
+}
+// packed row-best key: larger value wins, then the smaller column
+__device__ __forceinline__ unsigned long long mkkey(long long val, int col) {
+  return ((unsigned long long)(val + 1) << 12) | (unsigned long long)(4095 - col);
+}
+__device__ __forceinline__ int key_col(unsigned long long k) { return 4095 - (int)(k & 4095ull); }
+__device__ __forceinline__ long long key_val(unsigned long long k) { return (long long)(k >> 12) - 1; }
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// is the pair (role r1, role r2) rewritten by this iteration, and to what
+__device__ __forceinline__ bool in_s(int r1, int r2, bool merge) {
+  if (r1 == ROLE_NONE || r2 == ROLE_NONE) return false;
+  if ((r1 == ROLE_A && r2 == ROLE_B) || (r1 == ROLE_B && r2 == ROLE_A)) return true;
+  if (!merge) return false;
+  if ((r1 == ROLE_B && r2 == ROLE_FA) || (r1 == ROLE_FA && r2 == ROLE_B)) return true;
+  if ((r1 == ROLE_A && r2 == ROLE_FB) || (r1 == ROLE_FB && r2 == ROLE_A)) return true;
+  return false;
+}
+__device__ __forceinline__ int new_w(int r1, int r2, bool merge) {
+  const bool ab = (r1 == ROLE_A && r2 == ROLE_B) || (r1 == ROLE_B && r2 == ROLE_A);
+  return (ab && merge) ? W_PERM : W_FORB;
+}
+
+
+struct GreaterCnt {  // cmp() of the reference, :699-701: coverage descending
+  __host__ __device__ bool operator()(unsigned int x, unsigned int y) const { return (x >> 16) > (y >> 16); }
+};
+
+struct ChainCtx {
+  int n, P, Wp, G;
+  const unsigned long long* cover;  // word-major, stride G
+  const unsigned long long* alle;
+  long long plane_stride;
+  int planes;
+};
+
+__device__ __forceinline__ void pair_overlap(const ChainCtx& cx, int i, int j, int* o_out, int* d_out) {
+  int o = 0, d = 0;
+  for (int w = 0; w < cx.Wp; w++) {
+    const long long oi = (long long)w * cx.G + i, oj = (long long)w * cx.G + j;
+    const unsigned long long both = cx.cover[oi] & cx.cover[oj];
+    unsigned long long df = cx.alle[oi] ^ cx.alle[oj];
+    for (int pl = 1; pl < cx.planes; pl++) df |= cx.alle[pl * cx.plane_stride + oi] ^ cx.alle[pl * cx.plane_stride + oj];
+    o += __popcll(both);
+    d += __popcll(both & df);
+  }
+  *o_out = o;
+  *d_out = d;
+}
+
+__global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
+                                                  int C, int* __restrict__ qhead) {
+  extern __shared__ __align__(16) unsigned long long smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nmax = lds.nmax;
+  unsigned long long* bestF = smem;               // [nmax]  (S4: per-wave key buffers; S6: histograms)
+  unsigned long long* bestP = bestF + nmax;       // [nmax]
+  unsigned short* cl = (unsigned short*)(bestP + nmax);  // [nmax] clique id, later cluster id
+  unsigned short* listA = cl + nmax;
+  unsigned short* listB = listA + nmax;
+  unsigned short* listFa = listB + nmax;
+  unsigned short* listFb = listFa + nmax;
+  unsigned char* role = (unsigned char*)(listFb + nmax);  // [nmax]
+  unsigned char* dirty = role + nmax;                     // [nmax]
+  __shared__ int s_chain, s_cnt[4];
+  __shared__ long long s_rv[8];
+  __shared__ unsigned int s_rab[8];
+  __shared__ int s_asc[4][8];
+  __shared__ int s_back;
+
+  int* Wm = ws.W + (size_t)blockIdx.x * ws.nmax * ws.nmax;
+  IcPair* IC = ws.IC + (size_t)blockIdx.x * ws.nmax * ws.nmax;
+  double* rates = ws.rates + (size_t)blockIdx.x * 2 * ws.nmax;
+  unsigned int* sortbuf = ws.sortbuf + (size_t)blockIdx.x * 4 * ws.nmax;
+  int* tp_k = ws.tp_k + (size_t)blockIdx.x * ws.Pmax;
+  int* tp_gcid = ws.tp_gcid + (size_t)blockIdx.x * ws.Pmax * 8;
+  double* tp_cov = ws.tp_cov + (size_t)blockIdx.x * ws.Pmax * 8;
+  int* tp_cons = ws.tp_cons + (size_t)blockIdx.x * ws.Pmax * 8;
+  int* tp_consmap = ws.tp_consmap + (size_t)blockIdx.x * ws.Pmax * 8;
+  int* tp_ntup = ws.tp_ntup + (size_t)blockIdx.x * ws.Pmax;
+  int* tp_tuples = ws.tp_tuples + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
+  double* tp_score = ws.tp_score + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
+  unsigned short* tp_pred = ws.tp_pred + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
+
+  const int ploidy = db.ploidy;
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_chain = atomicAdd(qhead, 1);
+    __syncthreads();
+    const int qi = s_chain;
+    if (qi >= C) break;  // every wave of every workgroup reaches this
+    const int c = queue[qi];
+    if (db.status[c] != AHSOKA_ST_PHASED) continue;
+    const ChainMeta m = db.meta[c];
+    ChainCtx cx;
+    cx.n = db.nfin[c];
+    cx.P = db.npos[c];
+    cx.Wp = (cx.P + 63) >> 6;
+    cx.G = m.G;
+    cx.cover = db.cover + m.cov0;
+    cx.alle = db.alle + m.cov0;
+    cx.plane_stride = db.alle_plane_stride;
+    cx.planes = db.planes;
+    const int n = cx.n;
+
+    // ================= S4a: per-read local Hamming-rate estimates ==========
+    {
+      unsigned int* keybuf = (unsigned int*)bestF + (size_t)wv * nmax;  // 4 waves x nmax u32 = 16*nmax bytes
+      for (int i = wv; i < n; i += 4) {
+        int cnt = 0;
+        long long dall = 0, oall = 0;
+        for (int j = lane; j < n; j += 64) {
+          unsigned int key = 0xFFFFFFFFu;
+          if (j != i) {
+            int o, d;
+            pair_overlap(cx, i, j, &o, &d);
+            if (o >= db.min_overlap && o > 0) {
+              key = ((((unsigned)d << 20) / (unsigned)o) << 10) | (unsigned)o;
+              cnt++;
+              dall += d;
+              oall += o;
+            }
+          }
+          keybuf[j] = key;
+        }
+        cnt = wave_sum_i(cnt);
+        dall = wave_sum_ll(dall);
+        oall = wave_sum_ll(oall);
+        double s = 0.05, f = 0.5;
+        if (cnt > 0) {
+          int msel = cnt / ploidy;
+          if (msel == 0) msel = 1;
+          // smallest key T with #(key <= T) >= msel
+          unsigned int lo = 0, hi = 0x7FFFFFFFu;
+          while (lo < hi) {
+            const unsigned int mid = lo + ((hi - lo) >> 1);
+            int cle = 0;
+            for (int j = lane; j < n; j += 64) cle += (keybuf[j] <= mid) ? 1 : 0;
+            cle = wave_sum_i(cle);
+            if (cle >= msel) hi = mid;
+            else lo = mid + 1;
+          }
+          const unsigned int T = lo;
+          int cl_lt = 0;
+          long long ds = 0, os = 0;
+          for (int j = lane; j < n; j += 64) {
+            const unsigned int key = keybuf[j];
+            if (key < T) {
+              const unsigned int o = key & 1023u, rate = key >> 10;
+              const unsigned long long dd = ((unsigned long long)rate * o + ((1u << 20) - 1)) >> 20;
+              cl_lt++;
+              ds += (long long)dd;
+              os += o;
+            }
+          }
+          cl_lt = wave_sum_i(cl_lt);
+          ds = wave_sum_ll(ds);
+          os = wave_sum_ll(os);
+          const unsigned int oT = T & 1023u, rT = T >> 10;
+          const long long dT = (long long)(((unsigned long long)rT * oT + ((1u << 20) - 1)) >> 20);
+          ds += (long long)(msel - cl_lt) * dT;
+          os += (long long)(msel - cl_lt) * (long long)oT;
+          const long long dr = dall - ds, orr = oall - os;
+          s = os > 0 ? (double)ds / (double)os : 0.05;
+          f = orr > 0 ? (double)dr / (double)orr : 0.5;
+        }
+        if (s < 0.001) s = 0.001;
+        if (s > 0.999) s = 0.999;
+        if (f < 0.001) f = 0.001;
+        if (f > 0.999) f = 0.999;
+        if (lane == 0) {
+          rates[i] = s;
+          rates[n + i] = f;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ================= S4b: similarity matrix W ============================
+    for (int i = wv; i < n; i += 4) {
+      const double si = rates[i], fi = rates[n + i];
+      for (int j = lane; j < n; j += 64) {
+        int q = 0;
+        if (j != i) {
+          int o, d;
+          pair_overlap(cx, i, j, &o, &d);
+          if (o >= db.min_overlap && o > 0) {
+            // symmetric in (i,j): (a+b)*0.5 is commutative, so W[i][j] == W[j][i]
+            const double S = (si + rates[j]) * 0.5;
+            const double D = (fi + rates[n + j]) * 0.5;
+            const double t1 = (double)d * (det_log(S) - det_log(D));
+            const double t2 = (double)(o - d) * (det_log(1.0 - S) - det_log(1.0 - D));
+            q = quantise_score(t1 + t2);
+          }
+        }
+        Wm[(size_t)i * n + j] = q;
+        if (m.dump0 >= 0) db.score_dump[m.dump0 + (size_t)i * n + j] = q;
+      }
+    }
+    for (int u = tid; u < n; u += kBlock) {
+      cl[u] = (unsigned short)u;
+      dirty[u] = 0;
+      role[u] = ROLE_NONE;
+    }
+    __syncthreads();
+
+    // ================= S5 init: induced costs of every live edge ===========
+    // icf(ab) = max(w_ab,0) + sum_w min(w_aw,w_bw)+ ; icp likewise.  One wave per
+    // row a; the row's non-zero columns are compacted into LDS first so the
+    // triangle loop only visits actual neighbours of a.
+    {
+      unsigned short* nbr = listA + (size_t)wv * nmax;  // the four list arrays are free here: [4][nmax] u16
+      for (int a = wv; a < n; a += 4) {
+        int deg = 0;
+        for (int w0 = 0; w0 < n; w0 += 64) {
+          const int w = w0 + lane;
+          const bool nz = w < n && Wm[(size_t)a * n + w] != 0;
+          const unsigned long long mk = __ballot(nz);
+          if (nz) nbr[deg + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)w;
+          deg += __popcll(mk);
+        }
+        unsigned long long kF = 0, kP = 0;
+        for (int b0 = 0; b0 < n; b0 += 64) {
+          const int b = b0 + lane;
+          int wab = 0;
+          if (b < n) wab = Wm[(size_t)a * n + b];
+          long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
+          const bool live = wab != 0;
+          if (__ballot(live) != 0ull && b < n) {
+            for (int wi = 0; wi < deg; wi++) {
+              const int w = nbr[wi];
+              const long long waw = Wm[(size_t)a * n + w];  // wave-uniform
+              const long long wwb = Wm[(size_t)w * n + b];
+              f += icf_term(waw, wwb);
+              p += icp_term(waw, wwb);
+            }
+          }
+          if (b < n) {
+            IcPair v;
+            v.f = live ? f : -1;
+            v.p = live ? p : -1;
+            IC[(size_t)a * n + b] = v;
+            if (live) {
+              const unsigned long long k1 = mkkey(f, b), k2 = mkkey(p, b);
+              kF = k1 > kF ? k1 : kF;
+              kP = k2 > kP ? k2 : kP;
+            }
+          }
+        }
+        kF = wave_max_u64(kF);
+        kP = wave_max_u64(kP);
+        if (lane == 0) {
+          bestF[a] = kF;
+          bestP[a] = kP;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ================= S5 main loop ========================================
+    long long iters = 0;
+    for (;;) {
+      // ---- P1: edge with the largest icf and edge with the largest icp ----
+      long long vf = -1, vp = -1;
+      unsigned int abf = 0xFFFFFFFFu, abp = 0xFFFFFFFFu;
+      for (int u = tid; u < n; u += kBlock) {
+        const unsigned long long k1 = bestF[u], k2 = bestP[u];
+        if (k1) {
+          const int cc = key_col(k1);
+          const long long v = key_val(k1);
+          const unsigned int ab = u < cc ? ((unsigned)u << 16 | (unsigned)cc) : ((unsigned)cc << 16 | (unsigned)u);
+          if (v > vf || (v == vf && ab < abf)) { vf = v; abf = ab; }
+        }
+        if (k2) {
+          const int cc = key_col(k2);
+          const long long v = key_val(k2);
+          const unsigned int ab = u < cc ? ((unsigned)u << 16 | (unsigned)cc) : ((unsigned)cc << 16 | (unsigned)u);
+          if (v > vp || (v == vp && ab < abp)) { vp = v; abp = ab; }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const long long tv = __shfl_xor(vf, o, 64);
+        const unsigned int ta = __shfl_xor(abf, o, 64);
+        if (tv > vf || (tv == vf && ta < abf)) { vf = tv; abf = ta; }
+        const long long tv2 = __shfl_xor(vp, o, 64);
+        const unsigned int ta2 = __shfl_xor(abp, o, 64);
+        if (tv2 > vp || (tv2 == vp && ta2 < abp)) { vp = tv2; abp = ta2; }
+      }
+      if (lane == 0) {
+        s_rv[wv] = vf; s_rab[wv] = abf;
+        s_rv[4 + wv] = vp; s_rab[4 + wv] = abp;
+      }
+      __syncthreads();
+      vf = s_rv[0]; abf = s_rab[0]; vp = s_rv[4]; abp = s_rab[4];
+#pragma unroll
+      for (int k = 1; k < 4; k++) {
+        if (s_rv[k] > vf || (s_rv[k] == vf && s_rab[k] < abf)) { vf = s_rv[k]; abf = s_rab[k]; }
+        if (s_rv[4 + k] > vp || (s_rv[4 + k] == vp && s_rab[4 + k] < abp)) { vp = s_rv[4 + k]; abp = s_rab[4 + k]; }
+      }
+      if (vf < 0 || vp < 0) break;  // no live edge left (uniform)
+      iters++;
+      const bool merge = vf >= vp;
+      const int eu = merge ? (int)(abf >> 16) : (int)(abp >> 16);
+      const int ev = merge ? (int)(abf & 0xffff) : (int)(abp & 0xffff);
+      const int cu = cl[eu], cv = cl[ev];
+      if (tid < 4) s_cnt[tid] = 0;
+      __syncthreads();
+
+      // ---- P2: roles and member lists --------------------------------------
+      for (int z = tid; z < n; z += kBlock) {
+        int r = ROLE_NONE;
+        const int cz = cl[z];
+        if (cz == cu) r = ROLE_A;
+        else if (cz == cv) r = ROLE_B;
+        else if (merge) {
+          const bool fa = Wm[(size_t)eu * n + z] == W_FORB, fb = Wm[(size_t)ev * n + z] == W_FORB;
+          if (fa && !fb) r = ROLE_FA;
+          if (fb && !fa) r = ROLE_FB;
+        }
+        role[z] = (unsigned char)r;
+        if (r == ROLE_A) listA[atomicAdd(&s_cnt[0], 1)] = (unsigned short)z;
+        else if (r == ROLE_B) listB[atomicAdd(&s_cnt[1], 1)] = (unsigned short)z;
+        else if (r == ROLE_FA) listFa[atomicAdd(&s_cnt[2], 1)] = (unsigned short)z;
+        else if (r == ROLE_FB) listFb[atomicAdd(&s_cnt[3], 1)] = (unsigned short)z;
+      }
+      __syncthreads();
+      const int nA = s_cnt[0], nB = s_cnt[1], nFa = s_cnt[2], nFb = s_cnt[3];
+      const int nT = nA + nB + nFa + nFb;
+
+      // ---- P3: induced costs of the surviving live edges next to T ---------
+      for (int xi = 0; xi < nT; xi++) {
+        int x;
+        if (xi < nA) x = listA[xi];
+        else if (xi < nA + nB) x = listB[xi - nA];
+        else if (xi < nA + nB + nFa) x = listFa[xi - nA - nB];
+        else x = listFb[xi - nA - nB - nFa];
+        const int rx = role[x];
+        // columns rewritten in row x: two lists, each with its new weight
+        const unsigned short* L1 = nullptr; int n1 = 0, N1 = 0;
+        const unsigned short* L2 = nullptr; int n2 = 0;
+        if (rx == ROLE_A) { L1 = listB; n1 = nB; N1 = merge ? W_PERM : W_FORB; L2 = listFb; n2 = nFb; }
+        else if (rx == ROLE_B) { L1 = listA; n1 = nA; N1 = merge ? W_PERM : W_FORB; L2 = listFa; n2 = nFa; }
+        else if (rx == ROLE_FA) { L1 = listB; n1 = nB; N1 = W_FORB; }
+        else { L1 = listA; n1 = nA; N1 = W_FORB; }
+        for (int b = tid; b < n; b += kBlock) {
+          if (b == x) continue;
+          IcPair ic = IC[(size_t)x * n + b];
+          if (ic.f < 0) continue;  // not a live edge
+          const int rb = role[b];
+          if (in_s(rx, rb, merge)) continue;  // dies in P4
+          long long df = 0, dp = 0;
+          for (int pass = 0; pass < 2; pass++) {
+            const unsigned short* L = pass == 0 ? L1 : L2;
+            const int nl = pass == 0 ? n1 : n2;
+            const long long Nv = wval(pass == 0 ? N1 : W_FORB);
+            for (int wi = 0; wi < nl; wi++) {
+              const int w = L[wi];
+              const long long ov = wval(Wm[(size_t)x * n + w]);
+              const int wb_old = Wm[(size_t)w * n + b];
+              const int rw = role[w];
+              const long long wbo = wval(wb_old);
+              const long long wbn = in_s(rw, rb, merge) ? wval(new_w(rw, rb, merge)) : wbo;
+              df += icf_term(Nv, wbn) - icf_term(ov, wbo);
+              dp += icp_term(Nv, wbn) - icp_term(ov, wbo);
+            }
+          }
+          if (rb != ROLE_NONE) {
+            // triangles whose changed edge is (b,w) only: w in C(b) \ C(x)
+            const unsigned short* M1 = nullptr; int m1 = 0, Q1 = 0;
+            const unsigned short* M2 = nullptr; int m2 = 0;
+            if (rb == ROLE_A) { M1 = listB; m1 = nB; Q1 = merge ? W_PERM : W_FORB; M2 = listFb; m2 = nFb; }
+            else if (rb == ROLE_B) { M1 = listA; m1 = nA; Q1 = merge ? W_PERM : W_FORB; M2 = listFa; m2 = nFa; }
+            else if (rb == ROLE_FA) { M1 = listB; m1 = nB; Q1 = W_FORB; }
+            else { M1 = listA; m1 = nA; Q1 = W_FORB; }
+            for (int pass = 0; pass < 2; pass++) {
+              const unsigned short* L = pass == 0 ? M1 : M2;
+              const int nl = pass == 0 ? m1 : m2;
+              const long long Nv = wval(pass == 0 ? Q1 : W_FORB);
+              for (int wi = 0; wi < nl; wi++) {
+                const int w = L[wi];
+                if (w == x || in_s(rx, role[w], merge)) continue;  // (x,w) changes too: counted above
+                const long long ov = wval(Wm[(size_t)w * n + b]);
+                const long long xw = wval(Wm[(size_t)x * n + w]);
+                df += icf_term(Nv, xw) - icf_term(ov, xw);
+                dp += icp_term(Nv, xw) - icp_term(ov, xw);
+              }
+            }
+          }
+          if (df != 0 || dp != 0) {
+            ic.f += df;
+            ic.p += dp;
+            IC[(size_t)x * n + b] = ic;
+            if (rb == ROLE_NONE) IC[(size_t)b * n + x] = ic;
+          }
+          if (rb == ROLE_NONE) {
+            // row b is not rescanned: fold the new value into its row maximum
+            const unsigned long long k1 = bestF[b], k2 = bestP[b];
+            if ((k1 && key_col(k1) == x) || (k2 && key_col(k2) == x)) dirty[b] = 1;
+            else {
+              const unsigned long long nk1 = mkkey(ic.f, x), nk2 = mkkey(ic.p, x);
+              if (nk1 > k1) bestF[b] = nk1;
+              if (nk2 > k2) bestP[b] = nk2;
+            }
+          }
+        }
+      }
+      __syncthreads();
+
+      // ---- P4: rewrite the edges of S, merge the cliques --------------------
+      {
+        const int N1 = merge ? W_PERM : W_FORB;
+        const IcPair dead = {-1, -1};
+        for (int xi = 0; xi < nA; xi++) {
+          const int x = listA[xi];
+          for (int yi = tid; yi < nB + nFb; yi += kBlock) {
+            const int y = yi < nB ? listB[yi] : listFb[yi - nB];
+            const int N = yi < nB ? N1 : W_FORB;
+            Wm[(size_t)x * n + y] = N;
+            Wm[(size_t)y * n + x] = N;
+            IC[(size_t)x * n + y] = dead;
+            IC[(size_t)y * n + x] = dead;
+          }
+        }
+        for (int xi = 0; xi < nB; xi++) {
+          const int x = listB[xi];
+          for (int yi = tid; yi < nFa; yi += kBlock) {
+            const int y = listFa[yi];
+            Wm[(size_t)x * n + y] = W_FORB;
+            Wm[(size_t)y * n + x] = W_FORB;
+            IC[(size_t)x * n + y] = dead;
+            IC[(size_t)y * n + x] = dead;
+          }
+        }
+        if (merge)
+          for (int yi = tid; yi < nB; yi += kBlock) cl[listB[yi]] = (unsigned short)cu;
+      }
+      __syncthreads();
+
+      // ---- P5: rescan the rows of T and the rows flagged dirty --------------
+      for (int r = wv; r < n; r += 4) {
+        if (role[r] == ROLE_NONE && !dirty[r]) continue;  // wave-uniform
+        unsigned long long kF = 0, kP = 0;
+        for (int b = lane; b < n; b += 64) {
+          const IcPair v = IC[(size_t)r * n + b];
+          if (v.f >= 0) {
+            const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
+            kF = k1 > kF ? k1 : kF;
+            kP = k2 > kP ? k2 : kP;
+          }
+        }
+        kF = wave_max_u64(kF);
+        kP = wave_max_u64(kP);
+        if (lane == 0) {
+          bestF[r] = kF;
+          bestP[r] = kP;
+          dirty[r] = 0;
+        }
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- clusters: ordered by smallest member ------------------------------
+    // (bestF is free now: reuse as scratch)
+    unsigned int* scratch = (unsigned int*)bestF;  // [4*nmax] u32 available
+    for (int u = tid; u < n; u += kBlock) scratch[u] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int u = tid; u < n; u += kBlock) atomicMin(&scratch[cl[u]], (unsigned)u);
+    __syncthreads();
+    if (wv == 0) {
+      int base = 0;
+      for (int u0 = 0; u0 < n; u0 += 64) {
+        const int u = u0 + lane;
+        const bool lead = u < n && scratch[cl[u]] == (unsigned)u;
+        const unsigned long long mk = __ballot(lead);
+        if (lead) scratch[nmax + u] = base + __popcll(mk & ((1ull << lane) - 1ull));
+        base += __popcll(mk);
+      }
+      if (lane == 0) s_back = base;
+    }
+    __syncthreads();
+    const int K = s_back;
+    for (int u = tid; u < n; u += kBlock) {
+      const int kc = (int)scratch[nmax + scratch[cl[u]]];
+      db.fr_cluster[m.fr0 + u] = kc;
+      scratch[2 * (size_t)nmax + u] = (unsigned)kc;
+    }
+    __syncthreads();
+    for (int u = tid; u < n; u += kBlock) cl[u] = (unsigned short)scratch[2 * (size_t)nmax + u];
+    if (tid == 0) {
+      db.nclusters[c] = K;
+      db.niter[c] = iters;
+    }
+    __syncthreads();
+
+    // ================= S6: coverage, covMap, consensus =====================
+    const int P = cx.P;
+    const int nA_all = 1 << cx.planes;
+    {
+      unsigned int* hist = (unsigned int*)bestF + (size_t)wv * nmax;  // per wave, [K]
+      unsigned int* sb = sortbuf + (size_t)wv * ws.nmax;
+      for (int j = wv; j < P; j += 4) {
+        for (int k = lane; k < K; k += 64) hist[k] = 0;
+        const int wj = j >> 6, bj = j & 63;
+        int tot = 0;
+        for (int i = lane; i < n; i += 64) {
+          if ((cx.cover[(long long)wj * cx.G + i] >> bj) & 1ull) {
+            atomicAdd(&hist[cl[i]], 1u);
+            tot++;
+          }
+        }
+        tot = wave_sum_i(tot);
+        // clusters present at this position, ascending id (std::map order)
+        int M = 0;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+          const int k = k0 + lane;
+          const unsigned int h = k < K ? hist[k] : 0;
+          const unsigned long long mk = __ballot(h > 0);
+          if (h > 0) sb[M + __popcll(mk & ((1ull << lane) - 1ull))] = (h << 16) | (unsigned)k;
+          M += __popcll(mk);
+        }
+        // sort(): by coverage descending, std::sort from ascending-id order (:707-727)
+        __threadfence_block();  // sb is global memory shared between the lanes of this wave
+        if (lane < 8) s_asc[wv][lane] = lane < M ? (int)sb[lane] : 0;
+        if (lane == 0) gnu_sort(sb, M, GreaterCnt());
+        __threadfence_block();
+        // get_pos_to_clusters_map cut-off (:763-772)
+        int cut = M < 2 * ploidy ? M : 2 * ploidy;
+        {
+          const int lim = cut;
+          for (int i = ploidy; i < lim; i++) {
+            const double cv = (double)(sb[i] >> 16) / (double)tot;
+            if (cv < (1.0 / (8.0 * (double)ploidy))) { cut = i; break; }
+          }
+        }
+        // consensus of each selected cluster at this position (:604-655)
+        int mycons = 0;  // lane i < cut holds the consensus of covMap[j][i]
+        for (int ci = 0; ci < cut; ci++) {
+          const int cid = (int)(sb[ci] & 0xffffu);
+          int best_cnt = 0, best_a = 0;
+          for (int a = 0; a < nA_all; a++) {
+            int cnt = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+              const int i = i0 + lane;
+              bool hit = false;
+              if (i < n && cl[i] == cid) {
+                const long long o = (long long)wj * cx.G + i;
+                if ((cx.cover[o] >> bj) & 1ull) {
+                  int al = (int)((cx.alle[o] >> bj) & 1ull);
+                  for (int pl = 1; pl < cx.planes; pl++) al |= (int)((cx.alle[pl * cx.plane_stride + o] >> bj) & 1ull) << pl;
+                  hit = al == a;
+                }
+              }
+              cnt += __popcll(__ballot(hit));
+            }
+            if (cnt > best_cnt) { best_cnt = cnt; best_a = a; }  // lowest allele among maxima (:629-646)
+          }
+          if (lane == ci) mycons = best_a;
+        }
+        // tables for the threader
+        if (lane == 0) tp_k[j] = cut;
+        if (lane < cut) {
+          const unsigned int e = sb[lane];
+          tp_gcid[(size_t)j * 8 + lane] = (int)(e & 0xffffu);
+          tp_consmap[(size_t)j * 8 + lane] = mycons;
+          if (db.compaction_mode != 0) {
+            tp_cov[(size_t)j * 8 + lane] = (double)(e >> 16) / (double)tot;
+            tp_cons[(size_t)j * 8 + lane] = mycons;
+          } else {
+            // reference compaction (:379-402): coverage = i-th cluster present at the
+            // position in ascending id; consensus = i-th covMap cluster in ascending id
+            tp_cov[(size_t)j * 8 + lane] = (double)((unsigned)s_asc[wv][lane] >> 16) / (double)tot;
+          }
+        }
+        if (db.compaction_mode == 0) {
+          // rank of my cluster id among the selected ones
+          const int myid = lane < cut ? (int)(sb[lane] & 0xffffu) : 0x7fffffff;
+          int rank = 0;
+          for (int t = 0; t < cut; t++) {
+            const int oid = __shfl(myid, t, 64);
+            rank += (oid < myid) ? 1 : 0;
+          }
+          if (lane < cut) tp_cons[(size_t)j * 8 + rank] = mycons;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ================= S7: threading DP ====================================
+    // tuples of position j: ordered ploidy-tuples of local cluster indices,
+    // code = sum_i t_i * k^(ploidy-1-i), ascending; genotype-conform ones, or
+    // all of them when none conforms.
+    {
+      const long long Tmax = ws.Tmax;
+      if (wv == 0) {
+        for (int j = 0; j < P; j++) {
+          const int k = tp_k[j];
+          int T = 1;
+          for (int i = 0; i < ploidy; i++) T *= k;
+          // wanted allele counts
+          int want[kMaxAlleles];
+          for (int a = 0; a < kMaxAlleles; a++) want[a] = 0;
+          if (db.genotype) {
+            const int bub = db.pos[m.pos0 + j];
+            const long long a0 = db.allele_off[m.b0 + bub], a1 = db.allele_off[m.b0 + bub + 1];
+            for (long long a = a0; a < a1 && a - a0 < kMaxAlleles; a++) want[a - a0] = db.genotype[a];
+          } else {
+            want[0] = 1;
+            want[1] = 1;
+          }
+          int nconf = 0;
+          for (int c0 = 0; c0 < T; c0 += 64) {
+            const int code = c0 + lane;
+            bool ok = false;
+            if (code < T) {
+              int have[kMaxAlleles];
+              for (int a = 0; a < kMaxAlleles; a++) have[a] = 0;
+              int rem = code;
+              for (int i = 0; i < ploidy; i++) {
+                const int t = rem % k;
+                rem /= k;
+                const int al = tp_cons[(size_t)j * 8 + t];
+                for (int a = 0; a < kMaxAlleles; a++) have[a] += (a == al) ? 1 : 0;
+              }
+              ok = true;
+              for (int a = 0; a < kMaxAlleles; a++) ok = ok && (have[a] == want[a]);
+            }
+            const unsigned long long mk = __ballot(ok);
+            if (ok) tp_tuples[(size_t)j * Tmax + nconf + __popcll(mk & ((1ull << lane) - 1ull))] = code;
+            nconf += __popcll(mk);
+          }
+          if (nconf == 0) {
+            for (int code = lane; code < T; code += 64) tp_tuples[(size_t)j * Tmax + code] = code;
+            nconf = T;
+          }
+          if (lane == 0) tp_ntup[j] = nconf;
+        }
+      }
+      __syncthreads();
+      for (int j = 0; j < P; j++) {
+        const int k = tp_k[j], nt = tp_ntup[j];
+        const int kp = j > 0 ? tp_k[j - 1] : 1, ntp = j > 0 ? tp_ntup[j - 1] : 0;
+        for (int r = tid; r < nt; r += kBlock) {
+          int t[kMaxPloidy], g[kMaxPloidy];
+          int rem = tp_tuples[(size_t)j * Tmax + r];
+          for (int i = ploidy - 1; i >= 0; i--) { t[i] = rem % k; rem /= k; }
+          for (int i = 0; i < ploidy; i++) g[i] = tp_gcid[(size_t)j * 8 + t[i]];
+          double cc = 0.0;
+          for (int i = 0; i < ploidy; i++) {
+            int cn = 0;
+            for (int i2 = 0; i2 < ploidy; i2++) cn += (t[i2] == t[i]) ? 1 : 0;
+            const double cov = tp_cov[(size_t)j * 8 + t[i]];
+            const double lo = ((double)cn - 0.5) / (double)ploidy;
+            const double hi = ((double)cn + 0.5) / (double)ploidy;
+            if (cov < lo || cov > hi) cc += 1.0;
+          }
+          if (j == 0) {
+            tp_score[r] = cc;
+            tp_pred[r] = 0xffff;
+            continue;
+          }
+          double best = __builtin_inf();
+          int bq = 0;
+          for (int q = 0; q < ntp; q++) {
+            int remq = tp_tuples[(size_t)(j - 1) * Tmax + q];
+            int sw = 0;
+            for (int i = ploidy - 1; i >= 0; i--) {
+              const int tq = remq % kp;
+              remq /= kp;
+              sw += (tp_gcid[(size_t)(j - 1) * 8 + tq] != g[i]) ? 1 : 0;
+            }
+            const double s = tp_score[(size_t)(j - 1) * Tmax + q] + (db.switch_cost * (double)sw + (sw > 0 ? db.affine_cost : 0.0));
+            if (s < best) { best = s; bq = q; }
+          }
+          tp_score[(size_t)j * Tmax + r] = cc + best;
+          tp_pred[(size_t)j * Tmax + r] = (unsigned short)bq;
+        }
+        __syncthreads();
+      }
+      // ---- backtrace + S8 -------------------------------------------------
+      if (tid == 0) {
+        int cur = 0;
+        const int ntl = tp_ntup[P - 1];
+        for (int r = 1; r < ntl; r++)
+          if (tp_score[(size_t)(P - 1) * Tmax + r] < tp_score[(size_t)(P - 1) * Tmax + cur]) cur = r;
+        int* ha = db.hap_allele + (long long)ploidy * m.pos0;
+        int* hc = db.hap_cluster + (long long)ploidy * m.pos0;
+        for (int j = P - 1; j >= 0; j--) {
+          const int k = tp_k[j];
+          int rem = tp_tuples[(size_t)j * Tmax + cur];
+          for (int i = ploidy - 1; i >= 0; i--) {
+            const int t = rem % k;
+            rem /= k;
+            hc[(size_t)i * P + j] = tp_gcid[(size_t)j * 8 + t];
+            ha[(size_t)i * P + j] = tp_consmap[(size_t)j * 8 + t];  // new_consensus[j][c_id], :420-422
+          }
+          cur = tp_pred[(size_t)j * Tmax + cur];
+        }
+      }
+    }
+  }
+}
+
+size_t phase_lds_bytes(const PhaseLds& l) {
+  size_t b = (size_t)l.nmax * 8 * 2;  // bestF, bestP
+  b += (size_t)l.nmax * 2 * 5;        // cl + 4 lists
+  b += (size_t)l.nmax * 2;            // role, dirty
+  return (b + 15) & ~(size_t)15;
+}
+
+int phase_max_blocks_per_cu(const PhaseLds& l) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_phase, kBlock, phase_lds_bytes(l)) != hipSuccess) return 1;
+  return nb < 1 ? 1 : nb;
+}
+
+void launch_phase(const DeviceBatch& db, const SlotWorkspace& ws, const PhaseLds& l, const int* queue, int C, int* qhead,
+                  int slots, hipStream_t stream) {
+  hipLaunchKernelGGL(k_phase, dim3(slots), dim3(kBlock), phase_lds_bytes(l), stream, db, ws, l, queue, C, qhead);
+}
+
+}  // namespace ahk

@@ -1,0 +1,591 @@
+// phase_api.hip -- host side of the C-ABI (include/ahsoka_phase.h): validates
+// a ChainBatch, lays it out in HBM, launches the two kernels on one HIP
+// stream and copies the per-chain haplotype assignment back.
+//
+// Replaces one call of alignmentsToReadset (src/alignmentstoreadset.cpp:55).
+// There is NO CPU implementation of the path in this library: without a HIP
+// device every compute entry point returns AHSOKA_E_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "detmath.h"
+#include "gnusort.h"
+#include "phase_kernels.h"
+#include "../../include/ahsoka_phase.h"
+
+using namespace ahk;
+
+namespace {
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      std::fprintf(stderr, "ahsoka: HIP error %s at %s:%d (%s)\n", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+      return AHSOKA_E_HIP;                                                             \
+    }                                                                                  \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct ahsoka_device_batch {
+  ahsoka_phase_params prm;
+  int C = 0;
+  int device = 0;
+  std::vector<ChainMeta> meta;
+  std::vector<void*> allocs;
+  DeviceBatch db;
+  SlotWorkspace ws;
+  ReadsetLds rl;
+  PhaseLds pl;
+  int* queue = nullptr;
+  int* qhead = nullptr;
+  int slots = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  float k_ms[2] = {0, 0};
+  const char* k_names[2] = {"k_readset", "k_phase"};
+  long long sumB = 0, sumR = 0, sumG = 0, sumVm = 0, sumCov = 0, sumDump = 0;
+  size_t device_bytes = 0;
+  double last_ms = 0;
+
+  template <class T>
+  int dalloc(T** out, size_t count) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (hipMalloc(&p, bytes) != hipSuccess) return AHSOKA_E_NOMEM;
+    allocs.push_back(p);
+    device_bytes += bytes;
+    *out = (T*)p;
+    return AHSOKA_OK;
+  }
+  template <class T>
+  int dupload(const T** out, const T* src, size_t count) {
+    T* p = nullptr;
+    if (int e = dalloc(&p, count)) return e;
+    if (count && hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return AHSOKA_E_HIP;
+    *out = p;
+    return AHSOKA_OK;
+  }
+};
+
+extern "C" void ahsoka_default_params(ahsoka_phase_params* prm) {
+  if (!prm) return;
+  prm->ploidy = 2;
+  prm->min_mapq = 93;
+  prm->min_variants = 2;
+  prm->min_overlap = 1;
+  prm->switch_cost = 32.0;
+  prm->affine_switch_cost = 8.0;
+  prm->compaction_mode = 0;
+  prm->device = 0;
+  prm->want_stages = 0;
+}
+
+extern "C" int ahsoka_abi_version(void) { return AHSOKA_ABI_VERSION; }
+
+extern "C" int ahsoka_backend_info(char* buf, size_t buflen) {
+  if (!buf || buflen == 0) return AHSOKA_E_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    std::snprintf(buf, buflen, "hip:no-device");
+    return AHSOKA_E_NODEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, 0) != hipSuccess) {
+    std::snprintf(buf, buflen, "hip:no-device");
+    return AHSOKA_E_NODEVICE;
+  }
+  std::snprintf(buf, buflen, "hip:%s:%d:%d", prop.gcnArchName, prop.multiProcessorCount, ndev);
+  return AHSOKA_OK;
+}
+
+static int validate_batch(const ahsoka_chain_batch* in) {
+  if (!in || in->n_chains < 0) return AHSOKA_E_ARG;
+  if (in->n_chains == 0) return AHSOKA_OK;
+  if (!in->bubble_off || !in->allele_off || !in->apath_off || !in->node_off || !in->read_off || !in->rnode_off)
+    return AHSOKA_E_ARG;
+  const int C = in->n_chains;
+  if (in->bubble_off[0] != 0 || in->read_off[0] != 0 || in->node_off[0] != 0 || in->allele_off[0] != 0 ||
+      in->apath_off[0] != 0 || in->rnode_off[0] != 0)
+    return AHSOKA_E_ARG;
+  for (int c = 0; c < C; c++)
+    if (in->bubble_off[c + 1] < in->bubble_off[c] || in->read_off[c + 1] < in->read_off[c] ||
+        in->node_off[c + 1] < in->node_off[c])
+      return AHSOKA_E_ARG;
+  const long long SB = in->bubble_off[C], SR = in->read_off[C];
+  for (long long g = 0; g < SB; g++)
+    if (in->allele_off[g + 1] < in->allele_off[g]) return AHSOKA_E_ARG;
+  const long long SA = in->allele_off[SB];
+  for (long long a = 0; a < SA; a++)
+    if (in->apath_off[a + 1] < in->apath_off[a]) return AHSOKA_E_ARG;
+  for (long long r = 0; r < SR; r++)
+    if (in->rnode_off[r + 1] < in->rnode_off[r]) return AHSOKA_E_ARG;
+  if (in->apath_off[SA] > 0 && !in->apath_node) return AHSOKA_E_ARG;
+  if (SR > 0 && (!in->read_mapq || !in->read_name)) return AHSOKA_E_ARG;
+  if (in->rnode_off[SR] > 0 && !in->rnode) return AHSOKA_E_ARG;
+  // node indices must be chain-local and in range: the kernels index LDS with them
+  for (int c = 0; c < C; c++) {
+    const long long N = in->node_off[c + 1] - in->node_off[c];
+    for (long long g = in->bubble_off[c]; g < in->bubble_off[c + 1]; g++)
+      for (long long a = in->allele_off[g]; a < in->allele_off[g + 1]; a++)
+        for (long long e = in->apath_off[a]; e < in->apath_off[a + 1]; e++)
+          if (in->apath_node[e] < 0 || in->apath_node[e] >= N) return AHSOKA_E_ARG;
+    for (long long r = in->read_off[c]; r < in->read_off[c + 1]; r++) {
+      for (long long e = in->rnode_off[r]; e < in->rnode_off[r + 1]; e++)
+        if (in->rnode[e] < -1 || in->rnode[e] >= N) return AHSOKA_E_ARG;
+      if (in->read_name[r] < 0 || in->read_name[r] >= in->read_off[c + 1] - in->read_off[c]) return AHSOKA_E_ARG;
+    }
+  }
+  return AHSOKA_OK;
+}
+
+extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_phase_params* prm,
+                                   ahsoka_device_batch** handle) {
+  if (!in || !prm || !handle) return AHSOKA_E_ARG;
+  if (prm->ploidy < 2 || prm->ploidy > kMaxPloidy || prm->min_overlap < 0) return AHSOKA_E_ARG;
+  if (int e = validate_batch(in)) return e;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return AHSOKA_E_NODEVICE;
+  if (prm->device < 0 || prm->device >= ndev) return AHSOKA_E_ARG;
+  if (hipSetDevice(prm->device) != hipSuccess) return AHSOKA_E_NODEVICE;
+
+  ahsoka_device_batch* h = new (std::nothrow) ahsoka_device_batch();
+  if (!h) return AHSOKA_E_NOMEM;
+  h->prm = *prm;
+  h->device = prm->device;
+  const int C = h->C = in->n_chains;
+  std::memset(&h->db, 0, sizeof(h->db));
+  std::memset(&h->ws, 0, sizeof(h->ws));
+  int rc = AHSOKA_OK;
+  auto fail = [&](int code) {
+    ahsoka_batch_free(h);
+    return code;
+  };
+
+  // ---- per-chain metadata, name CSR, limits --------------------------------
+  h->meta.resize(C);
+  std::vector<long long> name_off;
+  std::vector<int> name_aln((size_t)in->read_off[C]);
+  int maxA = 2, maxG = 1, maxB = 1, maxN = 1;
+  long long vm = 0, fr = 0, cov = 0, dump = 0;
+  for (int c = 0; c < C; c++) {
+    ChainMeta& m = h->meta[c];
+    std::memset(&m, 0, sizeof(m));
+    m.b0 = in->bubble_off[c];
+    m.r0 = in->read_off[c];
+    m.n0 = in->node_off[c];
+    m.B = (int)(in->bubble_off[c + 1] - m.b0);
+    m.R = (int)(in->read_off[c + 1] - m.r0);
+    m.N = (int)(in->node_off[c + 1] - m.n0);
+    int G = 0;
+    for (int r = 0; r < m.R; r++) G = std::max(G, in->read_name[m.r0 + r] + 1);
+    m.G = G;
+    m.Wb = (m.B + 63) / 64;
+    m.name0 = (long long)name_off.size();
+    // counting sort of the chain's alignments by name id (stable: ascending alignment index)
+    std::vector<long long> cnt((size_t)G + 1, 0);
+    for (int r = 0; r < m.R; r++) cnt[in->read_name[m.r0 + r] + 1]++;
+    for (int g = 0; g < G; g++) cnt[g + 1] += cnt[g];
+    for (int g = 0; g <= G; g++) name_off.push_back(cnt[g]);
+    {
+      std::vector<long long> cur(cnt.begin(), cnt.end() - 1);
+      for (int r = 0; r < m.R; r++) name_aln[(size_t)m.r0 + cur[in->read_name[m.r0 + r]]++] = r;
+    }
+    bool unsupported = m.B > kMaxBubbles || m.N > kMaxNodes || G > kMaxNames || m.R > 131071;
+    for (long long g = m.b0; g < m.b0 + m.B; g++) {
+      const int na = (int)(in->allele_off[g + 1] - in->allele_off[g]);
+      if (na > kMaxAlleles) unsupported = true;
+      maxA = std::max(maxA, std::min(na, kMaxAlleles));
+      for (long long a = in->allele_off[g]; a < in->allele_off[g + 1]; a++) {
+        // std::includes is a multiset test (quirk Q5); the bit test equals it
+        // only for paths without repeated nodes
+        const long long p0 = in->apath_off[a], p1 = in->apath_off[a + 1];
+        for (long long e = p0; e < p1 && !unsupported; e++)
+          for (long long e2 = e + 1; e2 < p1; e2++)
+            if (in->apath_node[e] == in->apath_node[e2]) { unsupported = true; break; }
+      }
+    }
+    m.flags = unsupported ? 1 : 0;
+    m.vmat0 = vm;
+    m.fr0 = fr;
+    m.cov0 = cov;
+    m.pos0 = m.b0;
+    m.dump0 = -1;
+    vm += (long long)m.R * m.B;
+    fr += G;
+    cov += (long long)G * m.Wb;
+    if (prm->want_stages) {
+      m.dump0 = dump;
+      dump += (long long)std::min(G, kMaxReads) * std::min(G, kMaxReads);
+    }
+    if (!unsupported && m.B > 1) {
+      maxG = std::max(maxG, G);
+      maxB = std::max(maxB, m.B);
+      maxN = std::max(maxN, m.N);
+    }
+  }
+  h->sumB = in->bubble_off[C];
+  h->sumR = in->read_off[C];
+  h->sumG = fr;
+  h->sumVm = vm;
+  h->sumCov = cov;
+  h->sumDump = dump;
+  int planes = 1;
+  while ((1 << planes) < maxA) planes++;
+
+  // ---- inputs to HBM ---------------------------------------------------------
+  DeviceBatch& db = h->db;
+  const long long SB = in->bubble_off[C], SA = in->allele_off[SB], SP = in->apath_off[SA], SR = in->read_off[C],
+                  SL = in->rnode_off[SR];
+  if ((rc = h->dupload(&db.allele_off, (const long long*)in->allele_off, (size_t)SB + 1))) return fail(rc);
+  if ((rc = h->dupload(&db.apath_off, (const long long*)in->apath_off, (size_t)SA + 1))) return fail(rc);
+  if ((rc = h->dupload(&db.apath_node, (const int*)in->apath_node, (size_t)SP))) return fail(rc);
+  if (in->genotype) {
+    if ((rc = h->dupload(&db.genotype, (const int*)in->genotype, (size_t)SA))) return fail(rc);
+  } else {
+    db.genotype = nullptr;
+  }
+  if ((rc = h->dupload(&db.rnode_off, (const long long*)in->rnode_off, (size_t)SR + 1))) return fail(rc);
+  if ((rc = h->dupload(&db.rnode, (const int*)in->rnode, (size_t)SL))) return fail(rc);
+  if ((rc = h->dupload(&db.read_mapq, (const int*)in->read_mapq, (size_t)SR))) return fail(rc);
+  if ((rc = h->dupload(&db.meta, h->meta.data(), (size_t)C))) return fail(rc);
+  if ((rc = h->dupload(&db.name_off, name_off.data(), name_off.size()))) return fail(rc);
+  if ((rc = h->dupload(&db.name_aln, name_aln.data(), name_aln.size()))) return fail(rc);
+
+  // ---- per-chain outputs / k_readset workspace --------------------------------
+  if ((rc = h->dalloc(&db.vfull, (size_t)vm))) return fail(rc);
+  if ((rc = h->dalloc(&db.vpart, (size_t)vm))) return fail(rc);
+  if ((rc = h->dalloc(&db.status, (size_t)C))) return fail(rc);
+  if ((rc = h->dalloc(&db.nfin, (size_t)C))) return fail(rc);
+  if ((rc = h->dalloc(&db.npos, (size_t)C))) return fail(rc);
+  if ((rc = h->dalloc(&db.pos, (size_t)SB))) return fail(rc);
+  if ((rc = h->dalloc(&db.fr_name, (size_t)fr))) return fail(rc);
+  if ((rc = h->dalloc(&db.fr_cluster, (size_t)fr))) return fail(rc);
+  if ((rc = h->dalloc(&db.cover, (size_t)cov))) return fail(rc);
+  if ((rc = h->dalloc(&db.alle, (size_t)cov * planes))) return fail(rc);
+  db.alle_plane_stride = cov;
+  db.planes = planes;
+  if ((rc = h->dalloc(&db.hap_allele, (size_t)SB * prm->ploidy))) return fail(rc);
+  if ((rc = h->dalloc(&db.hap_cluster, (size_t)SB * prm->ploidy))) return fail(rc);
+  if ((rc = h->dalloc(&db.nclusters, (size_t)C))) return fail(rc);
+  if ((rc = h->dalloc(&db.niter, (size_t)C))) return fail(rc);
+  if (prm->want_stages) {
+    if ((rc = h->dalloc(&db.score_dump, (size_t)dump))) return fail(rc);
+  } else {
+    db.score_dump = nullptr;
+  }
+  db.ploidy = prm->ploidy;
+  db.min_mapq = prm->min_mapq;
+  db.min_variants = prm->min_variants;
+  db.min_overlap = prm->min_overlap;
+  db.compaction_mode = prm->compaction_mode;
+  db.switch_cost = prm->switch_cost;
+  db.affine_cost = prm->affine_switch_cost;
+
+  // ---- kernel geometry ----------------------------------------------------------
+  h->rl.wordsN = (maxN + 63) / 64;
+  h->rl.maxG = maxG;
+  h->rl.maxB = maxB;
+  h->pl.nmax = std::min(maxG, kMaxReads);
+  // 16-byte friendly capacity
+  h->pl.nmax = (h->pl.nmax + 7) & ~7;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, prm->device) != hipSuccess) return fail(AHSOKA_E_NODEVICE);
+  if (readset_lds_bytes(h->rl) > (size_t)prop.sharedMemPerBlock || phase_lds_bytes(h->pl) > (size_t)prop.sharedMemPerBlock)
+    return fail(AHSOKA_E_UNSUPPORTED);
+  const int per_cu = std::min(phase_max_blocks_per_cu(h->pl), 4);
+  int slots = std::min(C, prop.multiProcessorCount * per_cu);
+  if (slots < 1) slots = 1;
+  // slot workspace: W (4 B) + IC (16 B) per pair dominates; keep it under 60 % of free HBM
+  SlotWorkspace& ws = h->ws;
+  ws.nmax = h->pl.nmax;
+  ws.Pmax = maxB;
+  long long T = 1;
+  for (int i = 0; i < prm->ploidy; i++) T *= 2 * prm->ploidy;
+  ws.Tmax = T;
+  {
+    size_t freeb = 0, totalb = 0;
+    if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) return fail(AHSOKA_E_HIP);
+    const double per_slot = (double)ws.nmax * ws.nmax * 20.0 + (double)ws.Pmax * ws.Tmax * 14.0 + 1e5;
+    const long long fit = (long long)((double)freeb * 0.6 / per_slot);
+    if (fit < 1) return fail(AHSOKA_E_NOMEM);
+    if (slots > fit) slots = (int)fit;
+  }
+  h->slots = slots;
+  const size_t S = (size_t)slots;
+  if ((rc = h->dalloc(&ws.W, S * ws.nmax * ws.nmax))) return fail(rc);
+  if ((rc = h->dalloc(&ws.IC, S * ws.nmax * ws.nmax))) return fail(rc);
+  if ((rc = h->dalloc(&ws.rates, S * 2 * ws.nmax))) return fail(rc);
+  if ((rc = h->dalloc(&ws.tp_k, S * ws.Pmax))) return fail(rc);
+  if ((rc = h->dalloc(&ws.tp_gcid, S * ws.Pmax * 8))) return fail(rc);
+  if ((rc = h->dalloc(&ws.tp_cov, S * ws.Pmax * 8))) return fail(rc);
+  if ((rc = h->dalloc(&ws.tp_cons, S * ws.Pmax * 8))) return fail(rc);
+  if ((rc = h->dalloc(&ws.tp_consmap, S * ws.Pmax * 8))) return fail(rc);
+  if ((rc = h->dalloc(&ws.tp_ntup, S * ws.Pmax))) return fail(rc);
+  if ((rc = h->dalloc(&ws.tp_tuples, S * ws.Pmax * ws.Tmax))) return fail(rc);
+  if ((rc = h->dalloc(&ws.tp_score, S * ws.Pmax * ws.Tmax))) return fail(rc);
+  if ((rc = h->dalloc(&ws.tp_pred, S * ws.Pmax * ws.Tmax))) return fail(rc);
+  if ((rc = h->dalloc(&ws.sortbuf, S * 4 * ws.nmax))) return fail(rc);
+
+  // work queue: largest chains first (the reference orders chains by size too,
+  // src/polyassembly.cpp:136-140; here it balances the persistent grid)
+  std::vector<int> order(C);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    const double ca = (double)h->meta[a].G * h->meta[a].G * h->meta[a].B, cb = (double)h->meta[b].G * h->meta[b].G * h->meta[b].B;
+    return ca > cb;
+  });
+  {
+    const int* q = nullptr;
+    if ((rc = h->dupload(&q, order.data(), (size_t)C))) return fail(rc);
+    h->queue = const_cast<int*>(q);
+  }
+  if ((rc = h->dalloc(&h->qhead, 1))) return fail(rc);
+  if (hipStreamCreate(&h->stream) != hipSuccess) return fail(AHSOKA_E_HIP);
+  for (int i = 0; i < 3; i++)
+    if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(AHSOKA_E_HIP);
+  *handle = h;
+  return AHSOKA_OK;
+}
+
+extern "C" int ahsoka_phase_device(ahsoka_device_batch* h) {
+  if (!h) return AHSOKA_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->C == 0) return AHSOKA_OK;
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipMemsetAsync(h->qhead, 0, sizeof(int), h->stream));
+  HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+  launch_readset(h->db, h->C, h->rl, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+  launch_phase(h->db, h->ws, h->pl, h->queue, h->C, h->qhead, h->slots, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipEventElapsedTime(&h->k_ms[0], h->ev[0], h->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&h->k_ms[1], h->ev[1], h->ev[2]));
+  h->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return AHSOKA_OK;
+}
+
+extern "C" int ahsoka_batch_kernel_times(ahsoka_device_batch* h, int32_t* n, const char*** names, const float** ms) {
+  if (!h || !n || !names || !ms) return AHSOKA_E_ARG;
+  *n = 2;
+  *names = h->k_names;
+  *ms = h->k_ms;
+  return AHSOKA_OK;
+}
+
+namespace {
+template <class T>
+T* hostdup(const std::vector<T>& v) {
+  T* p = (T*)std::malloc(std::max<size_t>(1, v.size()) * sizeof(T));
+  if (p && !v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+  return p;
+}
+template <class T>
+int fetch(std::vector<T>& dst, const T* src, size_t count) {
+  dst.resize(count);
+  if (count && hipMemcpy(dst.data(), src, count * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) return AHSOKA_E_HIP;
+  return AHSOKA_OK;
+}
+}  // namespace
+
+extern "C" int ahsoka_batch_download(ahsoka_device_batch* h, ahsoka_phase_result* out) {
+  if (!h || !out) return AHSOKA_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  std::memset(out, 0, sizeof(*out));
+  const int C = h->C, p = h->prm.ploidy;
+  std::vector<int> status, nfin, npos, pos, ha, hc, ncl, frn, frc;
+  std::vector<int64_t> niter;
+  int rc;
+  if ((rc = fetch(status, (const int*)h->db.status, (size_t)C))) return rc;
+  if ((rc = fetch(nfin, (const int*)h->db.nfin, (size_t)C))) return rc;
+  if ((rc = fetch(npos, (const int*)h->db.npos, (size_t)C))) return rc;
+  if ((rc = fetch(pos, (const int*)h->db.pos, (size_t)h->sumB))) return rc;
+  if ((rc = fetch(ha, (const int*)h->db.hap_allele, (size_t)h->sumB * p))) return rc;
+  if ((rc = fetch(hc, (const int*)h->db.hap_cluster, (size_t)h->sumB * p))) return rc;
+  if ((rc = fetch(ncl, (const int*)h->db.nclusters, (size_t)C))) return rc;
+  if ((rc = fetch(niter, (const int64_t*)h->db.niter, (size_t)C))) return rc;
+  std::vector<int64_t> pos_off(C + 1, 0);
+  std::vector<int> opos, oha, ohc;
+  for (int c = 0; c < C; c++) {
+    const ChainMeta& m = h->meta[c];
+    const int P = status[c] == AHSOKA_ST_PHASED ? npos[c] : 0;
+    if (status[c] != AHSOKA_ST_PHASED) { nfin[c] = 0; ncl[c] = 0; niter[c] = 0; }
+    for (int j = 0; j < P; j++) opos.push_back(pos[m.pos0 + j]);
+    for (int i = 0; i < p; i++)
+      for (int j = 0; j < P; j++) {
+        oha.push_back(ha[(size_t)p * m.pos0 + (size_t)i * P + j]);
+        ohc.push_back(hc[(size_t)p * m.pos0 + (size_t)i * P + j]);
+      }
+    pos_off[c + 1] = (long long)opos.size();
+  }
+  out->n_chains = C;
+  out->ploidy = p;
+  out->status = hostdup(status);
+  out->pos_off = hostdup(pos_off);
+  out->pos = hostdup(opos);
+  out->hap_allele = hostdup(oha);
+  out->hap_cluster = hostdup(ohc);
+  out->n_reads = hostdup(nfin);
+  out->n_clusters = hostdup(ncl);
+  out->n_iterations = hostdup(niter);
+  if (h->prm.want_stages) {
+    std::vector<signed char> vf, vp;
+    if ((rc = fetch(vf, (const signed char*)h->db.vfull, (size_t)h->sumVm))) return rc;
+    if ((rc = fetch(vp, (const signed char*)h->db.vpart, (size_t)h->sumVm))) return rc;
+    if ((rc = fetch(frn, (const int*)h->db.fr_name, (size_t)h->sumG))) return rc;
+    if ((rc = fetch(frc, (const int*)h->db.fr_cluster, (size_t)h->sumG))) return rc;
+    std::vector<int> sd;
+    if ((rc = fetch(sd, (const int*)h->db.score_dump, (size_t)h->sumDump))) return rc;
+    std::vector<int64_t> vmat_off(C + 1, 0), fread_off(C + 1, 0), score_off(C + 1, 0);
+    std::vector<int8_t> ovf((size_t)h->sumVm), ovp((size_t)h->sumVm);
+    std::vector<int> ofn, ofc, osc;
+    for (int c = 0; c < C; c++) {
+      const ChainMeta& m = h->meta[c];
+      const bool ran = status[c] != AHSOKA_ST_SKIPPED_LE1 && status[c] != AHSOKA_ST_UNSUPPORTED;
+      // device layout is position-major [B][R]; the ABI (and the oracle) is [R][B]
+      for (int r = 0; r < m.R; r++)
+        for (int k = 0; k < m.B; k++) {
+          ovf[(size_t)m.vmat0 + (size_t)r * m.B + k] = ran ? vf[(size_t)m.vmat0 + (size_t)k * m.R + r] : -1;
+          ovp[(size_t)m.vmat0 + (size_t)r * m.B + k] = ran ? vp[(size_t)m.vmat0 + (size_t)k * m.R + r] : -1;
+        }
+      // k_readset writes the matrices before it knows whether S1 is empty; the
+      // oracle returns them in that case too.  S2 of a NO_FULL_MATCH chain is never run
+      // by either, but vpart is computed up-front here: mask it like the oracle does.
+      vmat_off[c + 1] = vmat_off[c] + (long long)m.R * m.B;
+      const int n = nfin[c];
+      for (int i = 0; i < n; i++) {
+        ofn.push_back(frn[m.fr0 + i]);
+        ofc.push_back(frc[m.fr0 + i]);
+      }
+      for (long long e = 0; e < (long long)n * n; e++) osc.push_back(sd[(size_t)m.dump0 + e]);
+      fread_off[c + 1] = (long long)ofn.size();
+      score_off[c + 1] = (long long)osc.size();
+    }
+    out->vmat_off = hostdup(vmat_off);
+    out->vfull = hostdup(ovf);
+    out->vpart = hostdup(ovp);
+    out->fread_off = hostdup(fread_off);
+    out->fread_name = hostdup(ofn);
+    out->fread_cluster = hostdup(ofc);
+    out->score_off = hostdup(score_off);
+    out->score_q = hostdup(osc);
+  }
+  out->elapsed_ms = h->last_ms;
+  out->kernel_ms = (double)h->k_ms[0] + (double)h->k_ms[1];
+  return AHSOKA_OK;
+}
+
+extern "C" void ahsoka_batch_free(ahsoka_device_batch* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (int i = 0; i < 3; i++)
+    if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" void ahsoka_result_free(ahsoka_phase_result* r) {
+  if (!r) return;
+  std::free(r->status); std::free(r->pos_off); std::free(r->pos); std::free(r->hap_allele);
+  std::free(r->hap_cluster); std::free(r->n_reads); std::free(r->n_clusters); std::free(r->n_iterations);
+  std::free(r->vmat_off); std::free(r->vfull); std::free(r->vpart);
+  std::free(r->fread_off); std::free(r->fread_name); std::free(r->fread_cluster);
+  std::free(r->score_off); std::free(r->score_q);
+  std::memset(r, 0, sizeof(*r));
+}
+
+extern "C" int ahsoka_phase_batch(const ahsoka_chain_batch* in, const ahsoka_phase_params* prm, ahsoka_phase_result* out) {
+  if (!in || !prm || !out) return AHSOKA_E_ARG;
+  auto t0 = std::chrono::steady_clock::now();
+  ahsoka_device_batch* h = nullptr;
+  int rc = ahsoka_batch_upload(in, prm, &h);
+  if (rc) return rc;
+  rc = ahsoka_phase_device(h);
+  if (!rc) rc = ahsoka_batch_download(h, out);
+  ahsoka_batch_free(h);
+  if (!rc) out->elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+
+// Algorithmic bytes of the INPUT side: everything read once,
+// 4-byte elements.  The output side, 4*(P + ploidy*P + 1) per chain, depends on
+// the result and is added by the caller.
+extern "C" int ahsoka_batch_bytes(const ahsoka_chain_batch* in, int32_t ploidy, int64_t* algorithmic_bytes) {
+  (void)ploidy;
+  if (!in || !algorithmic_bytes) return AHSOKA_E_ARG;
+  const int C = in->n_chains;
+  long long total = 0;
+  for (int c = 0; c < C; c++) {
+    const long long R = in->read_off[c + 1] - in->read_off[c];
+    const long long L = in->rnode_off[in->read_off[c + 1]] - in->rnode_off[in->read_off[c]];
+    const long long B = in->bubble_off[c + 1] - in->bubble_off[c];
+    const long long A = in->allele_off[in->bubble_off[c + 1]] - in->allele_off[in->bubble_off[c]];
+    const long long Pn = in->apath_off[in->allele_off[in->bubble_off[c + 1]]] - in->apath_off[in->allele_off[in->bubble_off[c]]];
+    total += 4 * ((R + 1) + L + R + R) + 4 * ((B + 1) + (A + 1) + Pn);
+  }
+  *algorithmic_bytes = total;
+  return AHSOKA_OK;
+}
+
+// ---- rendering, src/alignmentstoreadset.cpp:82-83,415-458 ---------------------
+extern "C" int64_t ahsoka_render_chain(const ahsoka_chain_batch* in, const ahsoka_phase_result* res, int32_t c, char* buf,
+                                       int64_t buflen) {
+  if (!in || !res || c < 0 || c >= in->n_chains || c >= res->n_chains) return AHSOKA_E_ARG;
+  std::string s;
+  const long long b0 = in->bubble_off[c], B = in->bubble_off[c + 1] - b0;
+  s += "chain id: " + std::to_string(in->chain_id ? in->chain_id[c] : c) + "\n";
+  s += "size of chain: " + std::to_string(B) + "\n";
+  if (res->status[c] == AHSOKA_ST_PHASED) {
+    const long long p0 = res->pos_off[c], P = res->pos_off[c + 1] - p0;
+    const int32_t* ha = res->hap_allele + (long long)res->ploidy * p0;
+    const int32_t* nid = in->node_id + in->node_off[c];
+    for (int i = 0; i < res->ploidy; i++) {
+      s += "haplotype " + std::to_string(i) + ":\n";
+      std::vector<int> used;
+      for (long long j = 0; j < P; j++) {
+        const int bub = res->pos[p0 + j];
+        const int cons = ha[(long long)i * P + j];
+        const long long a0 = in->allele_off[b0 + bub], a1 = in->allele_off[b0 + bub + 1];
+        if (cons < 0 || cons >= a1 - a0) continue;  // .at(cons) would throw in the reference (:424)
+        const long long e0 = in->apath_off[a0 + cons], e1 = in->apath_off[a0 + cons + 1];
+        for (long long e = e0; e + 1 < e1; e++) {  // the last node of a path is never printed (:433)
+          const int id = nid[in->apath_node[e]];
+          if (std::find(used.begin(), used.end(), id) != used.end()) continue;
+          const char sign = in->apath_sign ? (char)in->apath_sign[e] : '+';
+          s += std::to_string(id) + "(" + sign + "),";
+          used.push_back(id);
+        }
+      }
+      s += "\n";
+    }
+  }
+  if (buf && buflen > (int64_t)s.size()) std::memcpy(buf, s.c_str(), s.size() + 1);
+  return (int64_t)s.size();
+}
+
+// ---- host-only test hooks ------------------------------------------------------
+extern "C" int ahsoka_test_introsort_u32(uint32_t* v, int32_t n) {
+  if (!v || n < 0) return AHSOKA_E_ARG;
+  gnu_sort(v, n, LessHi16());
+  return AHSOKA_OK;
+}
+extern "C" double ahsoka_test_detlog(double x) { return det_log(x); }

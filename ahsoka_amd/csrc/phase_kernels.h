@@ -1,0 +1,117 @@
+// phase_kernels.h -- device-side data layout shared by the two kernels and the
+// host code that launches them.  gfx950 only.
+#pragma once
+#include <stdint.h>
+
+namespace ahk {
+
+// compiled-in device limits (a chain beyond them comes back AHSOKA_ST_UNSUPPORTED)
+constexpr int kMaxBubbles = 1023;   // positions are 10-bit fields of sort keys
+constexpr int kMaxNodes = 2048;     // per-alignment node bitset: 32 x u64 in LDS
+constexpr int kMaxNames = 4096;     // distinct read names per chain (k_readset LDS)
+constexpr int kMaxReads = 2048;     // reads in the final readset (k_phase LDS)
+constexpr int kMaxAlleles = 16;     // alleles per bubble (4 bit planes)
+constexpr int kMaxPloidy = 4;       // tuples = (2p)^p <= 4096
+constexpr int kBlock = 256;         // threads per workgroup (4 wavefronts)
+
+constexpr int32_t W_PERM = 0x7fffffff;
+constexpr int32_t W_FORB = (int32_t)0x80000000;
+
+struct alignas(16) IcPair {  // induced cost of forbidding / of making permanent
+  long long f, p;
+};
+
+// per-chain description, computed on the host at upload
+struct ChainMeta {
+  long long b0;        // first bubble (global index)
+  long long r0;        // first alignment
+  long long n0;        // first node
+  long long name0;     // first entry of name_off (per-chain CSR name -> alignments)
+  long long vmat0;     // offset of this chain's R*B match matrices
+  long long fr0;       // offset of per-final-read arrays (capacity = G)
+  long long cov0;      // offset of cover words (capacity G * Wb)
+  long long pos0;      // offset of pos[] output (capacity B)
+  long long dump0;     // offset into score dump (n*n) or -1
+  int B, R, N, G;      // bubbles, alignments, nodes, distinct names
+  int Wb;              // ceil(B/64): words of a position bit mask
+  int flags;           // bit0: chain exceeds a device limit
+  int pad0, pad1;
+};
+
+struct DeviceBatch {
+  // inputs (ChainBatch as uploaded)
+  const long long* allele_off;
+  const long long* apath_off;
+  const int* apath_node;
+  const int* genotype;  // may be null
+  const long long* rnode_off;
+  const int* rnode;
+  const int* read_mapq;
+  // derived on host
+  const ChainMeta* meta;
+  const long long* name_off;  // [sum(G)+C] per-chain CSR
+  const int* name_aln;        // [sum(R)] alignment index within chain
+  // k_readset workspace / outputs
+  signed char* vfull;  // [B][R] per chain, position-major
+  signed char* vpart;
+  int* status;         // [C]
+  int* nfin;           // [C] reads in the final readset
+  int* npos;           // [C] covered positions
+  int* pos;            // [sum B]
+  int* fr_name;        // [sum G]
+  unsigned long long* cover;  // [sum G*Wb] word-major: cover[w*G + i]
+  unsigned long long* alle;   // [planes][sum G*Wb]
+  long long alle_plane_stride;
+  int planes;
+  // k_phase outputs
+  int* hap_allele;     // [ploidy][P] per chain at ploidy*pos0
+  int* hap_cluster;
+  int* fr_cluster;     // [sum G]
+  int* nclusters;      // [C]
+  long long* niter;    // [C]
+  int* score_dump;     // optional
+  // params
+  int ploidy, min_mapq, min_variants, min_overlap, compaction_mode;
+  double switch_cost, affine_cost;
+};
+
+struct SlotWorkspace {
+  int* W;               // [slots][nmax*nmax]
+  IcPair* IC;           // [slots][nmax*nmax]
+  double* rates;        // [slots][2*nmax]   same_i, diff_i
+  // threading tables
+  int* tp_k;            // [slots][Pmax]         clusters per position
+  int* tp_gcid;         // [slots][Pmax*8]       covMap
+  double* tp_cov;       // [slots][Pmax*8]       coverage as HaploThreader indexes it
+  int* tp_cons;         // [slots][Pmax*8]       consensus as HaploThreader indexes it
+  int* tp_consmap;      // [slots][Pmax*8]       consensus of covMap[j][i]
+  int* tp_ntup;         // [slots][Pmax]
+  int* tp_tuples;       // [slots][Pmax*Tmax]
+  double* tp_score;     // [slots][Pmax*Tmax]
+  unsigned short* tp_pred;  // [slots][Pmax*Tmax]
+  unsigned int* sortbuf;    // [slots][nmax] cluster sort scratch (per wave slices)
+  long long nmax, Pmax, Tmax;
+};
+
+}  // namespace ahk
+
+// ---- launchers (defined next to their kernels) ------------------------------
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+namespace ahk {
+struct ReadsetLds {
+  int wordsN;  // u64 words of a node bitset (max over the batch)
+  int maxG;    // max distinct names
+  int maxB;
+};
+struct PhaseLds {
+  int nmax;  // capacity of the per-read LDS arrays
+};
+size_t readset_lds_bytes(const ReadsetLds& l);
+void launch_readset(const DeviceBatch& db, int C, const ReadsetLds& l, hipStream_t stream);
+size_t phase_lds_bytes(const PhaseLds& l);
+void launch_phase(const DeviceBatch& db, const SlotWorkspace& ws, const PhaseLds& l, const int* queue, int C, int* qhead,
+                  int slots, hipStream_t stream);
+int phase_max_blocks_per_cu(const PhaseLds& l);
+}  // namespace ahk
+#endif
