@@ -107,7 +107,7 @@ ABI_SYMBOLS = [
     "ahsoka_default_params", "ahsoka_backend_info", "ahsoka_abi_version", "ahsoka_phase_batch",
     "ahsoka_result_free", "ahsoka_batch_upload", "ahsoka_phase_device", "ahsoka_batch_download",
     "ahsoka_batch_free", "ahsoka_batch_kernel_times", "ahsoka_batch_bytes", "ahsoka_render_chain",
-    "ahsoka_ingest", "ahsoka_batch_host_free", "ahsoka_synth_batch", "ahsoka_synth_write_text",
+    "ahsoka_ingest", "ahsoka_ingest_dump", "ahsoka_batch_host_free", "ahsoka_synth_batch", "ahsoka_synth_write_text",
     "ahsoka_test_introsort_u32", "ahsoka_test_detlog",
 ]
 
@@ -142,6 +142,7 @@ def lib() -> C.CDLL:
     L.ahsoka_render_chain.argtypes = [C.POINTER(CChainBatch), C.POINTER(CPhaseResult), C.c_int32, C.c_char_p, C.c_int64]
     L.ahsoka_render_chain.restype = C.c_int64
     L.ahsoka_ingest.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.POINTER(CChainBatch))]
+    L.ahsoka_ingest_dump.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     L.ahsoka_batch_host_free.argtypes = [C.POINTER(CChainBatch)]
     L.ahsoka_batch_host_free.restype = None
     L.ahsoka_synth_batch.argtypes = [C.POINTER(CSynthSpec), C.POINTER(C.POINTER(CChainBatch))]
@@ -301,6 +302,10 @@ def ingest(gfa: str, gaf: str) -> ChainBatch:
     out = C.POINTER(CChainBatch)()
     _check(lib().ahsoka_ingest(gfa.encode(), gaf.encode(), C.byref(out)), "ahsoka_ingest")
     return ChainBatch(cptr=out)
+
+
+def ingest_dump(gfa: str, gaf: str, out_path: str) -> None:
+    _check(lib().ahsoka_ingest_dump(gfa.encode(), gaf.encode(), out_path.encode()), "ahsoka_ingest_dump")
 
 
 @dataclass

@@ -1,0 +1,117 @@
+"""Multi-GPU sharding of the phasing path: one process per GPU.
+
+Chains are independent (each iteration of the chain loop of
+``alignmentsToReadset`` -- src/alignmentstoreadset.cpp:75-490 -- reads only its
+own alignments and allele paths), so the data path needs no collective: a
+static partition of the chain list over the ranks, every rank phases its shard
+on its own MI355X, and ONE gather of the per-chain result records to rank 0 at
+the end (``torch.distributed`` -- backend "nccl" is RCCL over xGMI on ROCm, "gloo"
+in the CPU tests).  Rank 0 puts the records back into the global chain order, so
+the rendered output does not depend on the number of GPUs.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .capi import PhaseResult
+
+
+def block_partition(n_items: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous blocks (first, count); sizes differ by at most one."""
+    base, extra = divmod(n_items, world)
+    out, first = [], 0
+    for r in range(world):
+        cnt = base + (1 if r < extra else 0)
+        out.append((first, cnt))
+        first += cnt
+    return out
+
+
+def lpt_partition(costs: Sequence[float], world: int) -> List[np.ndarray]:
+    """Cost-weighted static partition (longest processing time first) for skewed
+    chain sizes (BASELINE config 5): returns, per rank, the global chain indices
+    it owns, each list ascending.  Deterministic: ties go to the lower rank."""
+    costs = np.asarray(costs, dtype=np.float64)
+    order = np.argsort(-costs, kind="stable")
+    load = np.zeros(world)
+    owner = np.empty(len(costs), dtype=np.int64)
+    for i in order:
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += costs[i]
+    return [np.flatnonzero(owner == r) for r in range(world)]
+
+
+def chain_cost(n_reads: np.ndarray, n_bubbles: np.ndarray) -> np.ndarray:
+    """Work model of one chain: the pair matrix dominates (R^2 per position
+    word) plus the R*B match matrices."""
+    r = n_reads.astype(np.float64)
+    b = n_bubbles.astype(np.float64)
+    return r * r * np.maximum(1.0, b / 64.0) + r * b
+
+
+def pack_records(res: PhaseResult, max_chains: int, max_pos: int) -> np.ndarray:
+    """Fixed-size int32 record per chain: [status, P, pos[max_pos], hap[ploidy*max_pos]]."""
+    p = res.ploidy
+    width = 2 + max_pos + p * max_pos
+    rec = np.full((max_chains, width), -1, dtype=np.int32)
+    for c in range(res.n_chains):
+        pos = res.chain_pos(c)
+        P = len(pos)
+        rec[c, 0] = res.status[c]
+        rec[c, 1] = P
+        rec[c, 2:2 + P] = pos
+        haps = res.chain_haps(c)
+        for i in range(p):
+            rec[c, 2 + max_pos + i * max_pos: 2 + max_pos + i * max_pos + P] = haps[i]
+    return rec
+
+
+def unpack_records(rec: np.ndarray, ploidy: int, max_pos: int):
+    """-> (status, pos_off, pos, hap_allele) in the order of the rows of rec
+    (rows with status -1 are padding and are dropped)."""
+    keep = rec[:, 0] >= 0
+    rec = rec[keep]
+    status = rec[:, 0].copy()
+    P = rec[:, 1].astype(np.int64)
+    pos_off = np.concatenate([[0], np.cumsum(P)]).astype(np.int64)
+    pos = np.concatenate([rec[c, 2:2 + P[c]] for c in range(len(rec))] or [np.zeros(0, np.int32)]).astype(np.int32)
+    hap = []
+    for c in range(len(rec)):
+        for i in range(ploidy):
+            o = 2 + max_pos + i * max_pos
+            hap.append(rec[c, o:o + P[c]])
+    hap_allele = np.concatenate(hap or [np.zeros(0, np.int32)]).astype(np.int32)
+    return status, pos_off, pos, hap_allele
+
+
+def gather_to_rank0(res: PhaseResult, owned: np.ndarray, n_total: int, max_pos: int, device=None, group=None):
+    """The single collective of the path.  ``owned`` = global chain indices of this
+    rank's shard, in the order the shard was phased.  Returns on rank 0
+    (status, pos_off, pos, hap_allele) for all n_total chains in global chain
+    order, on other ranks None."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([len(owned)], dtype=torch.int64, device=dev), group=group)
+    max_chains = int(max(int(c.item()) for c in counts))
+    rec = pack_records(res, max_chains, max_pos)
+    idx = np.full(max_chains, -1, dtype=np.int32)
+    idx[: len(owned)] = owned
+    payload = torch.from_numpy(np.concatenate([idx[:, None], rec], axis=1)).to(dev)
+    bufs = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+    dist.gather(payload, bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    allrec = torch.cat(bufs, dim=0).cpu().numpy()
+    allrec = allrec[allrec[:, 0] >= 0]
+    order = np.argsort(allrec[:, 0], kind="stable")
+    allrec = allrec[order]
+    assert len(allrec) == n_total and (allrec[:, 0] == np.arange(n_total)).all(), "shards do not tile the chain list"
+    return unpack_records(allrec[:, 1:], res.ploidy, max_pos)

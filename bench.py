@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- bubbles/s phased on the BASELINE.json headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (k_readset + k_phase, then the result
+download and, for N > 1, the single gather to rank 0) over one synthetic batch
+whose inputs are already resident in HBM.  Workload at every N: BASELINE.json
+configs[2] -- 10k chains x 50 bubbles x 1000 reads/chain, ploidy 2 -- PER GPU
+(weak scaling: rank r generates chains [r*10k, (r+1)*10k) of one global
+deterministic workload; no data-path collective).
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline      dominant kernel (k_phase): algorithmic bytes / its mean HIP-event
+                duration on the launch stream, against 8 TB/s HBM
+  cpu_baseline  the CPU oracle ("port": oracle/oracle.cpp, NOT the upstream
+                binary, which cannot be built here) on a bounded sample of the
+                same workload, timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", help="BASELINE config (c3 = headline); others for experiments")
+    ap.add_argument("--chains", type=int, default=0, help="override chains per GPU (experiments only)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="chains timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    from ahsoka_amd import capi, shard
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the phasing path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = dict(capi.CONFIGS[args.config])
+    per_gpu = args.chains if args.chains > 0 else cfg["n_chains"]
+    cfg["n_chains"] = per_gpu
+    cfg["first_chain"] = rank * per_gpu
+    ploidy = cfg["ploidy"]
+    t_gen = time.time()
+    batch = capi.synth_batch(**cfg)
+    t_gen = time.time() - t_gen
+    arr = batch.arrays()
+    bubble_off = arr["bubble_off"]
+    max_pos = int(np.diff(bubble_off).max())
+    prm = capi.default_params(ploidy=ploidy, device=local_rank)
+
+    # host buffers -> HBM once; the timed region starts with inputs resident
+    t_up = time.time()
+    dev = capi.DeviceBatch(batch, prm)
+    t_up = time.time() - t_up
+    owned = np.arange(rank * per_gpu, (rank + 1) * per_gpu)
+
+    def step():
+        dev.phase()
+        res = dev.download()
+        gathered = None
+        if world > 1:
+            gathered = shard.gather_to_rank0(res, owned, per_gpu * world, max_pos, device=device)
+        return res, gathered
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    k_phase_ms, k_readset_ms = [], []
+    fence()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(args.steps):
+        res, gathered = step()
+        kt = dev.kernel_times_ms()
+        k_phase_ms.append(kt["k_phase"])
+        k_readset_ms.append(kt["k_readset"])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    phased = res.phased_bubbles(bubble_off)
+    if world > 1:
+        t = torch.tensor([phased], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_phased = int(t.item())
+    else:
+        total_phased = phased
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = total_phased / (elapsed / args.steps)
+
+    if rank == 0:
+        # algorithmic bytes of one launch: inputs once + outputs once
+        P_total = int(res.pos_off[-1])
+        n_phased = int((res.status == capi.ST_PHASED).sum())
+        alg_bytes = batch.algorithmic_input_bytes(ploidy) + 4 * (P_total + ploidy * P_total + n_phased)
+        kp = float(np.mean(k_phase_ms))
+        achieved = alg_bytes / (kp * 1e-3) / 1e9
+        out = {
+            "metric": "bubbles/s phased (ploidy 2, 1000 reads/chain)",
+            "value": value,
+            "unit": "bubbles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[2]: {per_gpu} chains x {cfg['n_bubbles']} bubbles x "
+                            f"{cfg['n_reads']} reads/chain, ploidy {ploidy}, per GPU",
+                "config_name": args.config,
+                "chains_per_gpu": per_gpu,
+                "parallelism": f"chain-shard x{world}, one gather",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_phase",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms": kp,
+                "k_readset_ms": float(np.mean(k_readset_ms)),
+            },
+            "phased_bubbles_per_step": total_phased,
+            "phased_chains_rank0": n_phased,
+            "upload_s": t_up,
+            "synth_s": t_gen,
+            "backend": capi.backend_info(),
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(cfg, prm, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    dev.free()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, prm, n_sample):
+    """The CPU oracle timed on this box's host cores on the first n_sample chains
+    of the same workload.  This is the checker used as a yardstick, never part
+    of the measured GPU path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    from ahsoka_amd import capi
+
+    c = dict(cfg)
+    c["n_chains"] = n_sample
+    c["first_chain"] = 0
+    b = capi.synth_batch(**c)
+    cores = max(1, min(n_sample, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    r = ob.phase_batch(b, prm, n_threads=cores)
+    dt = time.perf_counter() - t0
+    bubbles = r.phased_bubbles(b.arrays()["bubble_off"])
+    return {
+        "value": bubbles / dt,
+        "unit": "bubbles/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {n_sample} chains of the same workload ({bubbles} bubbles) in {dt:.2f} s wall, "
+                  f"{cores} threads; CPU re-statement (oracle/oracle.cpp), not the upstream binary",
+    }
+
+
+if __name__ == "__main__":
+    main()

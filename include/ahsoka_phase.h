@@ -198,6 +198,10 @@ int64_t ahsoka_render_chain(const ahsoka_chain_batch* in, const ahsoka_phase_res
  */
 int ahsoka_ingest(const char* gfa_path, const char* gaf_path, ahsoka_chain_batch** out);
 void ahsoka_batch_host_free(ahsoka_chain_batch* b);
+/* Text dump of what the ingest derived (CHAIN/BUBBLE/ALLELE/ALN/ORDER lines, the
+ * format of oracle/ref_harness.cpp): pins the ingest against the reference's own
+ * parsers and feeds <o>-bubbleinfo.txt (src/polyassembly.cpp:95-110). */
+int ahsoka_ingest_dump(const char* gfa_path, const char* gaf_path, const char* out_path);
 
 /*
  * Deterministic synthetic workload: C chains of

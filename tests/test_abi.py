@@ -1,0 +1,97 @@
+"""The C-ABI library loads without a GPU and exports every symbol that
+include/ahsoka_phase.h declares; compute entry points refuse to run without a
+device instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from ahsoka_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ahsoka_phase.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ahsoka_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(capi.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    for name in declared_symbols():
+        assert hasattr(L, name), name
+    assert L.ahsoka_abi_version() == 1
+
+
+def test_default_params_are_the_reference_literals():
+    p = capi.default_params()
+    # src/alignmentstoreadset.cpp:306,158,311,320
+    assert (p.ploidy, p.min_mapq, p.min_variants, p.min_overlap) == (2, 93, 2, 1)
+    assert (p.switch_cost, p.affine_switch_cost, p.compaction_mode) == (32.0, 8.0, 0)
+
+
+def test_argument_errors():
+    L = capi.lib()
+    assert L.ahsoka_phase_batch(None, None, None) == capi.E_ARG
+    assert L.ahsoka_synth_batch(None, None) == capi.E_ARG
+    bad = capi.synth_spec(n_chains=1, n_bubbles=0, n_reads=1)
+    out = C.POINTER(capi.CChainBatch)()
+    assert L.ahsoka_synth_batch(C.byref(bad), C.byref(out)) == capi.E_ARG
+    with pytest.raises(capi.AhsokaError):
+        capi.ingest("/nonexistent.gfa", "/nonexistent.gaf")
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    b = capi.synth_batch(**capi.CONFIGS["c1"])
+    with pytest.raises(capi.AhsokaError) as e:
+        capi.phase_batch(b)
+    assert e.value.code == capi.E_NODEVICE
+    assert capi.backend_info() == "hip:no-device"
+
+
+def test_batch_validation_rejects_out_of_range_nodes():
+    import numpy as np
+
+    b = capi.synth_batch(n_chains=1, n_bubbles=3, n_reads=4, seed=1)
+    a = b.arrays()
+    a["rnode"] = a["rnode"].copy()
+    a["rnode"][0] = 10_000
+    bad = capi.ChainBatch(arrays={k: v for k, v in a.items() if v is not None})
+    r = capi.CPhaseResult()
+    prm = capi.default_params()
+    rc = capi.lib().ahsoka_phase_batch(bad.ptr(), C.byref(prm), C.byref(r))
+    assert rc in (capi.E_ARG, capi.E_NODEVICE)
+    h = C.c_void_p()
+    assert capi.lib().ahsoka_batch_upload(bad.ptr(), C.byref(prm), C.byref(h)) == capi.E_ARG
+
+
+def test_synth_is_deterministic_and_shardable():
+    import numpy as np
+
+    full = capi.synth_batch(n_chains=6, n_bubbles=7, n_reads=30, seed=42).arrays()
+    lo = capi.synth_batch(n_chains=4, n_bubbles=7, n_reads=30, seed=42, first_chain=0).arrays()
+    hi = capi.synth_batch(n_chains=2, n_bubbles=7, n_reads=30, seed=42, first_chain=4).arrays()
+    np.testing.assert_array_equal(full["rnode"], np.concatenate([lo["rnode"], hi["rnode"]]))
+    np.testing.assert_array_equal(full["read_mapq"], np.concatenate([lo["read_mapq"], hi["read_mapq"]]))
+    np.testing.assert_array_equal(full["node_id"], np.concatenate([lo["node_id"], hi["node_id"]]))
+    np.testing.assert_array_equal(full["chain_id"], np.arange(6))
+    assert full["read_mapq"].min() >= 90 and full["read_mapq"].max() <= 99
+
+
+def test_algorithmic_bytes_formula():
+    b = capi.synth_batch(n_chains=3, n_bubbles=5, n_reads=10, seed=7)
+    a = b.arrays()
+    R, L, B = 30, len(a["rnode"]), 15
+    A, Pn = 2 * B, 3 * 2 * B
+    exp = 4 * ((R + 3) + L + R + R) + 4 * ((B + 3) + (A + 3) + Pn)
+    assert b.algorithmic_input_bytes() == exp

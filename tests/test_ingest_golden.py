@@ -1,0 +1,93 @@
+"""Host ingest (ahsoka_amd/csrc/ingest.cpp) against the reference's own parsers
+and bubble finder: chain / bubble numbering, Bubble{source,sink,inner}, allele
+paths and orientation signs, the per-chain alignment lists with the
+(int)(id*100) identity and the number of copies the reference stores, and the
+size_sorting order.  Expected files were produced by oracle/_ref/ref_dump =
+/root/reference/src/{graph,alignmentreader,chainstoreadset}.cpp compiled
+unchanged (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from ahsoka_amd import capi
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("stem", ["c1", "toy"])
+def test_dump_equals_reference(stem, tmp_path):
+    out = str(tmp_path / "dump.txt")
+    capi.ingest_dump(os.path.join(GOLD, stem + ".gfa"), os.path.join(GOLD, stem + ".gaf"), out)
+    assert open(out).read() == open(os.path.join(GOLD, stem + ".ref.txt")).read()
+
+
+def _parse(path):
+    chains, alleles, alns, order = {}, {}, {}, []
+    for ln in open(path):
+        t = ln.split()
+        if t[0] == "CHAIN":
+            chains[int(t[1])] = int(t[2])
+        elif t[0] == "ALLELE":
+            n = int(t[4])
+            alleles.setdefault((int(t[1]), int(t[2])), []).append(([int(x) for x in t[5:5 + n]], t[6 + n:]))
+        elif t[0] == "ALN":
+            n = int(t[5])
+            alns.setdefault(int(t[1]), []).append((t[2], int(t[3]), [int(x) for x in t[6:6 + n]]))
+        elif t[0] == "ORDER":
+            order = [int(x) for x in t[1:]]
+    return chains, alleles, alns, order
+
+
+@pytest.mark.parametrize("stem", ["c1", "toy"])
+def test_batch_equals_reference(stem):
+    chains, alleles, alns, order = _parse(os.path.join(GOLD, stem + ".ref.txt"))
+    b = capi.ingest(os.path.join(GOLD, stem + ".gfa"), os.path.join(GOLD, stem + ".gaf"))
+    a = b.arrays()
+    assert list(a["chain_id"]) == order
+    for ci, cid in enumerate(order):
+        b0, b1 = a["bubble_off"][ci], a["bubble_off"][ci + 1]
+        assert b1 - b0 == chains[cid]
+        nid = a["node_id"][a["node_off"][ci]:a["node_off"][ci + 1]]
+        for k in range(b1 - b0):
+            exp = alleles[(cid, k)]
+            a0, a1 = a["allele_off"][b0 + k], a["allele_off"][b0 + k + 1]
+            assert a1 - a0 == len(exp)
+            for ai in range(a1 - a0):
+                e0, e1 = a["apath_off"][a0 + ai], a["apath_off"][a0 + ai + 1]
+                assert list(nid[a["apath_node"][e0:e1]]) == exp[ai][0]
+                assert [chr(c) for c in a["apath_sign"][e0:e1 - 1]] == exp[ai][1]
+        r0, r1 = a["read_off"][ci], a["read_off"][ci + 1]
+        exp_al = alns.get(cid, [])
+        assert r1 - r0 == len(exp_al)
+        names = {}
+        for r in range(r0, r1):
+            name, mapq, nodes = exp_al[r - r0]
+            assert a["read_mapq"][r] == mapq
+            loc = a["rnode"][a["rnode_off"][r]:a["rnode_off"][r + 1]]
+            back = [int(nid[x]) if x >= 0 else None for x in loc]
+            assert all(bk is None or bk == nd for bk, nd in zip(back, nodes)) and len(back) == len(nodes)
+            # nodes mapped to -1 are exactly those that are not nodes of this chain
+            assert all((nd in set(nid.tolist())) == (bk is not None) for bk, nd in zip(back, nodes))
+            names.setdefault(name, len(names))
+            assert a["read_name"][r] == names[name]
+
+
+def test_identity_truncation():
+    """(int)(stof(id)*100): 0.935 -> 93, 0.931 -> 93, 1 -> 100, 0.92 -> 92"""
+    b = capi.ingest(os.path.join(GOLD, "toy.gfa"), os.path.join(GOLD, "toy.gaf"))
+    a = b.arrays()
+    assert sorted(set(a["read_mapq"].tolist())) == [92, 93, 94, 95, 96, 97, 98, 99, 100]
+
+
+def test_parse_errors(tmp_path):
+    gfa = tmp_path / "x.gfa"
+    gaf = tmp_path / "x.gaf"
+    gfa.write_text("S\tutg000001l\tA\nS\tutg000002l\tA\nL\tutg000001l\t+\tutg000002l\t+\t0M\n")
+    gaf.write_text("r\t1\t0\t1\t+\t>utg000001l\t1\t0\t1\t1\t1\t60\tNM:i:0\tAS:f:0\tdv:f:0\n")  # 15 tokens
+    with pytest.raises(capi.AhsokaError) as e:
+        capi.ingest(str(gfa), str(gaf))
+    assert e.value.code == capi.E_PARSE
+    gaf.write_text("r\t1\t0\t1\t+\t>utg000001l\t1\t0\t1\t1\t1\t60\tNM:i:0\tAS:f:0\tdv:f:0\tid:f:0.95\n")
+    b = capi.ingest(str(gfa), str(gaf))
+    assert b.n_chains == 0  # a single edge forms no bubble
