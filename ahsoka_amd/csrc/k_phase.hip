@@ -31,6 +31,21 @@
 #include "phase_kernels.h"
 #include "../../include/ahsoka_phase.h"
 
+// Diagnostic build only (-DAHK_TIMING): workgroup 0 prints, for its first chain,
+// the shader-clock cycles spent in each phase of the cluster-editing loop.
+#ifdef AHK_TIMING
+#define AHK_T(slot)                                      \
+  do {                                                   \
+    if (tid == 0) {                                      \
+      const long long _t = (long long)clock64();         \
+      tacc[slot] += _t - tlast;                          \
+      tlast = _t;                                        \
+    }                                                    \
+  } while (0)
+#else
+#define AHK_T(slot) do {} while (0)
+#endif
+
 namespace ahk {
 
 constexpr long long BIGV = 1ll << 40;
@@ -88,6 +103,11 @@ __device__ __forceinline__ int new_w(int r1, int r2, bool merge) {
 }
 
 
+// induced costs are stored once per edge, at [min(a,b)][max(a,b)]
+__device__ __forceinline__ size_t ic_index(int a, int b, int n) {
+  return a < b ? (size_t)a * n + b : (size_t)b * n + a;
+}
+
 struct GreaterCnt {  // cmp() of the reference, :699-701: coverage descending
   __host__ __device__ bool operator()(unsigned int x, unsigned int y) const { return (x >> 16) > (y >> 16); }
 };
@@ -126,16 +146,20 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
   unsigned short* listB = listA + nmax;
   unsigned short* listFa = listB + nmax;
   unsigned short* listFb = listFa + nmax;
-  unsigned char* role = (unsigned char*)(listFb + nmax);  // [nmax]
-  unsigned char* dirty = role + nmax;                     // [nmax]
-  __shared__ int s_chain, s_cnt[4];
-  __shared__ long long s_rv[8];
+  unsigned short* rowbuf = listFb + nmax;                 // [4][nmax] per-wave column buffers
+  unsigned short* dlist = rowbuf + 4 * (size_t)nmax;      // [nmax] rows whose maximum must be rescanned
+  unsigned int* stalew = (unsigned int*)(dlist + nmax);   // [nmax/32] bit per row: already in dlist
+  unsigned char* role = (unsigned char*)(stalew + (nmax + 31) / 32);  // [nmax]
+  __shared__ int s_chain, s_cnt[4], s_nd, s_items;
+  __shared__ long long s_rv[16];
   __shared__ unsigned int s_rab[8];
   __shared__ int s_asc[4][8];
   __shared__ int s_back;
 
   int* Wm = ws.W + (size_t)blockIdx.x * ws.nmax * ws.nmax;
   IcPair* IC = ws.IC + (size_t)blockIdx.x * ws.nmax * ws.nmax;
+  unsigned long long* LV = ws.live + (size_t)blockIdx.x * ws.nmax * ((ws.nmax + 63) / 64);
+  unsigned int* items_glb = ws.items + (size_t)blockIdx.x * ws.nmax * ws.nmax;
   double* rates = ws.rates + (size_t)blockIdx.x * 2 * ws.nmax;
   unsigned int* sortbuf = ws.sortbuf + (size_t)blockIdx.x * 4 * ws.nmax;
   int* tp_k = ws.tp_k + (size_t)blockIdx.x * ws.Pmax;
@@ -266,7 +290,6 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
     }
     for (int u = tid; u < n; u += kBlock) {
       cl[u] = (unsigned short)u;
-      dirty[u] = 0;
       role[u] = ROLE_NONE;
     }
     __syncthreads();
@@ -274,9 +297,12 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
     // ================= S5 init: induced costs of every live edge ===========
     // icf(ab) = max(w_ab,0) + sum_w min(w_aw,w_bw)+ ; icp likewise.  One wave per
     // row a; the row's non-zero columns are compacted into LDS first so the
-    // triangle loop only visits actual neighbours of a.
+    // triangle loop only visits actual neighbours of a.  Also writes the row's
+    // live-edge bitmap (one u64 per 64 columns): from here on an edge is live
+    // iff its bit is set, and IC holds garbage for dead pairs.
+    const int nw = (n + 63) >> 6;
     {
-      unsigned short* nbr = listA + (size_t)wv * nmax;  // the four list arrays are free here: [4][nmax] u16
+      unsigned short* nbr = rowbuf + (size_t)wv * nmax;
       for (int a = wv; a < n; a += 4) {
         int deg = 0;
         for (int w0 = 0; w0 < n; w0 += 64) {
@@ -285,15 +311,15 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
           const unsigned long long mk = __ballot(nz);
           if (nz) nbr[deg + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)w;
           deg += __popcll(mk);
+          if (lane == 0) LV[(size_t)a * nw + (w0 >> 6)] = mk;
         }
         unsigned long long kF = 0, kP = 0;
-        for (int b0 = 0; b0 < n; b0 += 64) {
-          const int b = b0 + lane;
-          int wab = 0;
-          if (b < n) wab = Wm[(size_t)a * n + b];
-          long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
-          const bool live = wab != 0;
-          if (__ballot(live) != 0ull && b < n) {
+        for (int i0 = 0; i0 < deg; i0 += 64) {
+          const int i = i0 + lane;
+          if (i < deg) {
+            const int b = nbr[i];
+            const int wab = Wm[(size_t)a * n + b];
+            long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
             for (int wi = 0; wi < deg; wi++) {
               const int w = nbr[wi];
               const long long waw = Wm[(size_t)a * n + w];  // wave-uniform
@@ -301,17 +327,15 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
               f += icf_term(waw, wwb);
               p += icp_term(waw, wwb);
             }
-          }
-          if (b < n) {
-            IcPair v;
-            v.f = live ? f : -1;
-            v.p = live ? p : -1;
-            IC[(size_t)a * n + b] = v;
-            if (live) {
-              const unsigned long long k1 = mkkey(f, b), k2 = mkkey(p, b);
-              kF = k1 > kF ? k1 : kF;
-              kP = k2 > kP ? k2 : kP;
+            if (a < b) {
+              IcPair v;
+              v.f = f;
+              v.p = p;
+              IC[(size_t)a * n + b] = v;
             }
+            const unsigned long long k1 = mkkey(f, b), k2 = mkkey(p, b);
+            kF = k1 > kF ? k1 : kF;
+            kP = k2 > kP ? k2 : kP;
           }
         }
         kF = wave_max_u64(kF);
@@ -322,48 +346,120 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
         }
       }
     }
+    for (int u = tid; u < (n + 31) / 32; u += kBlock) stalew[u] = 0;
+    if (tid < 4) s_cnt[tid] = 0;
+    if (tid == 0) { s_nd = 0; s_items = 0; }
     __syncthreads();
+    if (lds.stop_after == 2) continue;  // profiling aid only (results invalid)
 
     // ================= S5 main loop ========================================
     long long iters = 0;
+#ifdef AHK_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)clock64(), nretry = 0, nresc = 0, sumT = 0;
+#endif
     for (;;) {
       // ---- P1: edge with the largest icf and edge with the largest icp ----
-      long long vf = -1, vp = -1;
-      unsigned int abf = 0xFFFFFFFFu, abp = 0xFFFFFFFFu;
-      for (int u = tid; u < n; u += kBlock) {
-        const unsigned long long k1 = bestF[u], k2 = bestP[u];
-        if (k1) {
-          const int cc = key_col(k1);
-          const long long v = key_val(k1);
-          const unsigned int ab = u < cc ? ((unsigned)u << 16 | (unsigned)cc) : ((unsigned)cc << 16 | (unsigned)u);
-          if (v > vf || (v == vf && ab < abf)) { vf = v; abf = ab; }
+      // Row maxima may be stale upper bounds (their maximum decreased in an
+      // earlier iteration and the row was not revisited): a stale row is
+      // rescanned only when its bound ties the global maximum ("lazy deletion").
+      long long vf, vp;
+      unsigned int abf, abp;
+      for (;;) {
+        vf = -1; vp = -1;
+        abf = 0xFFFFFFFFu; abp = 0xFFFFFFFFu;
+        long long sF = -1, sP = -1;
+        for (int u = tid; u < n; u += kBlock) {
+          const unsigned long long k1 = bestF[u], k2 = bestP[u];
+          const bool st = (stalew[u >> 5] >> (u & 31)) & 1u;
+          if (k1) {
+            const int cc = key_col(k1);
+            const long long v = key_val(k1);
+            const unsigned int ab = u < cc ? ((unsigned)u << 16 | (unsigned)cc) : ((unsigned)cc << 16 | (unsigned)u);
+            if (v > vf || (v == vf && ab < abf)) { vf = v; abf = ab; }
+            if (st && v > sF) sF = v;
+          }
+          if (k2) {
+            const int cc = key_col(k2);
+            const long long v = key_val(k2);
+            const unsigned int ab = u < cc ? ((unsigned)u << 16 | (unsigned)cc) : ((unsigned)cc << 16 | (unsigned)u);
+            if (v > vp || (v == vp && ab < abp)) { vp = v; abp = ab; }
+            if (st && v > sP) sP = v;
+          }
         }
-        if (k2) {
-          const int cc = key_col(k2);
-          const long long v = key_val(k2);
-          const unsigned int ab = u < cc ? ((unsigned)u << 16 | (unsigned)cc) : ((unsigned)cc << 16 | (unsigned)u);
-          if (v > vp || (v == vp && ab < abp)) { vp = v; abp = ab; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const long long tv = __shfl_xor(vf, o, 64);
+          const unsigned int ta = __shfl_xor(abf, o, 64);
+          if (tv > vf || (tv == vf && ta < abf)) { vf = tv; abf = ta; }
+          const long long tv2 = __shfl_xor(vp, o, 64);
+          const unsigned int ta2 = __shfl_xor(abp, o, 64);
+          if (tv2 > vp || (tv2 == vp && ta2 < abp)) { vp = tv2; abp = ta2; }
+          const long long t3 = __shfl_xor(sF, o, 64), t4 = __shfl_xor(sP, o, 64);
+          sF = t3 > sF ? t3 : sF;
+          sP = t4 > sP ? t4 : sP;
         }
-      }
+        if (lane == 0) {
+          s_rv[wv] = vf; s_rab[wv] = abf;
+          s_rv[4 + wv] = vp; s_rab[4 + wv] = abp;
+          s_rv[8 + wv] = sF; s_rv[12 + wv] = sP;
+        }
+        __syncthreads();
+        vf = s_rv[0]; abf = s_rab[0]; vp = s_rv[4]; abp = s_rab[4];
+        sF = s_rv[8]; sP = s_rv[12];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const long long tv = __shfl_xor(vf, o, 64);
-        const unsigned int ta = __shfl_xor(abf, o, 64);
-        if (tv > vf || (tv == vf && ta < abf)) { vf = tv; abf = ta; }
-        const long long tv2 = __shfl_xor(vp, o, 64);
-        const unsigned int ta2 = __shfl_xor(abp, o, 64);
-        if (tv2 > vp || (tv2 == vp && ta2 < abp)) { vp = tv2; abp = ta2; }
-      }
-      if (lane == 0) {
-        s_rv[wv] = vf; s_rab[wv] = abf;
-        s_rv[4 + wv] = vp; s_rab[4 + wv] = abp;
-      }
-      __syncthreads();
-      vf = s_rv[0]; abf = s_rab[0]; vp = s_rv[4]; abp = s_rab[4];
-#pragma unroll
-      for (int k = 1; k < 4; k++) {
-        if (s_rv[k] > vf || (s_rv[k] == vf && s_rab[k] < abf)) { vf = s_rv[k]; abf = s_rab[k]; }
-        if (s_rv[4 + k] > vp || (s_rv[4 + k] == vp && s_rab[4 + k] < abp)) { vp = s_rv[4 + k]; abp = s_rab[4 + k]; }
+        for (int k = 1; k < 4; k++) {
+          if (s_rv[k] > vf || (s_rv[k] == vf && s_rab[k] < abf)) { vf = s_rv[k]; abf = s_rab[k]; }
+          if (s_rv[4 + k] > vp || (s_rv[4 + k] == vp && s_rab[4 + k] < abp)) { vp = s_rv[4 + k]; abp = s_rab[4 + k]; }
+          sF = s_rv[8 + k] > sF ? s_rv[8 + k] : sF;
+          sP = s_rv[12 + k] > sP ? s_rv[12 + k] : sP;
+        }
+        const bool need = (sF >= 0 && sF == vf) || (sP >= 0 && sP == vp);
+        AHK_T(0);
+        if (!need) break;  // uniform
+        // collect the stale rows whose bound ties a maximum, rescan them exactly
+        for (int u = tid; u < n; u += kBlock) {
+          if (!((stalew[u >> 5] >> (u & 31)) & 1u)) continue;
+          const unsigned long long k1 = bestF[u], k2 = bestP[u];
+          if ((k1 && key_val(k1) == vf) || (k2 && key_val(k2) == vp)) dlist[atomicAdd(&s_nd, 1)] = (unsigned short)u;
+        }
+        __syncthreads();
+        {
+          const int nd = s_nd;
+          unsigned short* rb_buf = rowbuf + (size_t)wv * nmax;
+          for (int di = wv; di < nd; di += 4) {
+            const int r = dlist[di];
+            const unsigned long long bmw = lane < nw ? LV[(size_t)r * nw + lane] : 0ull;
+            int Lc = 0;
+            for (int k = 0; k < nw; k++) {
+              const unsigned long long word = __shfl(bmw, k, 64);
+              if (word == 0ull) continue;
+              const bool lv = (word >> lane) & 1ull;
+              if (lv) rb_buf[Lc + __popcll(word & ((1ull << lane) - 1ull))] = (unsigned short)((k << 6) + lane);
+              Lc += __popcll(word);
+            }
+            unsigned long long kF = 0, kP = 0;
+            for (int i = lane; i < Lc; i += 64) {
+              const int b = rb_buf[i];
+              const IcPair v = IC[ic_index(r, b, n)];
+              const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
+              kF = k1 > kF ? k1 : kF;
+              kP = k2 > kP ? k2 : kP;
+            }
+            kF = wave_max_u64(kF);
+            kP = wave_max_u64(kP);
+            if (lane == 0) {
+              bestF[r] = kF;
+              bestP[r] = kP;
+              atomicAnd(&stalew[r >> 5], ~(1u << (r & 31)));
+            }
+          }
+        }
+        __syncthreads();
+#ifdef AHK_TIMING
+        nretry++; nresc += s_nd;
+#endif
+        AHK_T(1);
+        if (tid == 0) s_nd = 0;  // next use is behind the reduction barrier above
       }
       if (vf < 0 || vp < 0) break;  // no live edge left (uniform)
       iters++;
@@ -371,10 +467,8 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
       const int eu = merge ? (int)(abf >> 16) : (int)(abp >> 16);
       const int ev = merge ? (int)(abf & 0xffff) : (int)(abp & 0xffff);
       const int cu = cl[eu], cv = cl[ev];
-      if (tid < 4) s_cnt[tid] = 0;
-      __syncthreads();
 
-      // ---- P2: roles and member lists --------------------------------------
+      // ---- P2: roles and member lists (s_cnt was zeroed before the last barrier)
       for (int z = tid; z < n; z += kBlock) {
         int r = ROLE_NONE;
         const int cz = cl[z];
@@ -394,39 +488,86 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
       __syncthreads();
       const int nA = s_cnt[0], nB = s_cnt[1], nFa = s_cnt[2], nFb = s_cnt[3];
       const int nT = nA + nB + nFa + nFb;
+      AHK_T(2);
+#ifdef AHK_TIMING
+      sumT += nT;
+#endif
 
-      // ---- P3: induced costs of the surviving live edges next to T ---------
-      for (int xi = 0; xi < nT; xi++) {
-        int x;
-        if (xi < nA) x = listA[xi];
-        else if (xi < nA + nB) x = listB[xi - nA];
-        else if (xi < nA + nB + nFa) x = listFa[xi - nA - nB];
-        else x = listFb[xi - nA - nB - nFa];
-        const int rx = role[x];
-        // columns rewritten in row x: two lists, each with its new weight
-        const unsigned short* L1 = nullptr; int n1 = 0, N1 = 0;
-        const unsigned short* L2 = nullptr; int n2 = 0;
-        if (rx == ROLE_A) { L1 = listB; n1 = nB; N1 = merge ? W_PERM : W_FORB; L2 = listFb; n2 = nFb; }
-        else if (rx == ROLE_B) { L1 = listA; n1 = nA; N1 = merge ? W_PERM : W_FORB; L2 = listFa; n2 = nFa; }
-        else if (rx == ROLE_FA) { L1 = listB; n1 = nB; N1 = W_FORB; }
-        else { L1 = listA; n1 = nA; N1 = W_FORB; }
-        for (int b = tid; b < n; b += kBlock) {
-          if (b == x) continue;
-          IcPair ic = IC[(size_t)x * n + b];
-          if (ic.f < 0) continue;  // not a live edge
-          const int rb = role[b];
-          if (in_s(rx, rb, merge)) continue;  // dies in P4
+      // ---- P3a: list the surviving live edges (x,b), x in T --------------------
+      // One wave per row x: read the row's live bitmap, clear the bits of the
+      // edges that die now, append the survivors to a workgroup-wide item list
+      // (first 2*nmax items in LDS, the rest in this slot's HBM scratch).
+      {
+        unsigned int* items_lds = (unsigned int*)rowbuf;
+        const int cap = 2 * nmax;
+        for (int xi = wv; xi < nT; xi += 4) {
+          int x;
+          if (xi < nA) x = listA[xi];
+          else if (xi < nA + nB) x = listB[xi - nA];
+          else if (xi < nA + nB + nFa) x = listFa[xi - nA - nB];
+          else x = listFb[xi - nA - nB - nFa];
+          const int rx = role[x];
+          const unsigned long long bmw = lane < nw ? LV[(size_t)x * nw + lane] : 0ull;
+          for (int k = 0; k < nw; k++) {
+            const unsigned long long word = __shfl(bmw, k, 64);
+            if (word == 0ull) continue;
+            const int b = (k << 6) + lane;
+            const bool bit = (word >> lane) & 1ull;
+            const int rbk = role[b];
+            const bool dies = bit && in_s(rx, rbk, merge);
+            // an edge with both ends in T is listed once, from its lower end
+            const bool lv = bit && !dies && (rbk == ROLE_NONE || x < b);
+            const unsigned long long dm = __ballot(dies), mk = __ballot(lv);
+            if (dm != 0ull && lane == 0) LV[(size_t)x * nw + k] = word & ~dm;
+            if (mk == 0ull) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_items, __popcll(mk));
+            base = __shfl(base, 0, 64);
+            if (lv) {
+              const int idx = base + __popcll(mk & ((1ull << lane) - 1ull));
+              const unsigned int it = ((unsigned)x << 16) | (unsigned)b;
+              if (idx < cap) items_lds[idx] = it;
+              else items_glb[idx - cap] = it;
+            }
+          }
+          if (lane == 0) {  // the row maximum of x is rebuilt from scratch in P3b
+            bestF[x] = 0;
+            bestP[x] = 0;
+            atomicAnd(&stalew[x >> 5], ~(1u << (x & 31)));
+          }
+        }
+      }
+      __syncthreads();
+      AHK_T(5);
+
+      // ---- P3b: one lane per listed edge: apply this iteration's changes --------
+      {
+        const unsigned int* items_lds = (const unsigned int*)rowbuf;
+        const int cap = 2 * nmax;
+        const int M = s_items;
+        for (int i = tid; i < M; i += kBlock) {
+          const unsigned int it = i < cap ? items_lds[i] : items_glb[i - cap];
+          const int x = (int)(it >> 16), b = (int)(it & 0xffffu);
+          const int rx = role[x], rb = role[b];
+          IcPair ic = IC[ic_index(x, b, n)];
+          // columns rewritten in row x: two lists, each with its new weight
+          const unsigned short* L1 = nullptr; int n1 = 0, N1 = 0;
+          const unsigned short* L2 = nullptr; int n2 = 0;
+          if (rx == ROLE_A) { L1 = listB; n1 = nB; N1 = merge ? W_PERM : W_FORB; L2 = listFb; n2 = nFb; }
+          else if (rx == ROLE_B) { L1 = listA; n1 = nA; N1 = merge ? W_PERM : W_FORB; L2 = listFa; n2 = nFa; }
+          else if (rx == ROLE_FA) { L1 = listB; n1 = nB; N1 = W_FORB; }
+          else { L1 = listA; n1 = nA; N1 = W_FORB; }
           long long df = 0, dp = 0;
           for (int pass = 0; pass < 2; pass++) {
             const unsigned short* L = pass == 0 ? L1 : L2;
             const int nl = pass == 0 ? n1 : n2;
             const long long Nv = wval(pass == 0 ? N1 : W_FORB);
+#pragma unroll 4
             for (int wi = 0; wi < nl; wi++) {
               const int w = L[wi];
               const long long ov = wval(Wm[(size_t)x * n + w]);
-              const int wb_old = Wm[(size_t)w * n + b];
+              const long long wbo = wval(Wm[(size_t)w * n + b]);
               const int rw = role[w];
-              const long long wbo = wval(wb_old);
               const long long wbn = in_s(rw, rb, merge) ? wval(new_w(rw, rb, merge)) : wbo;
               df += icf_term(Nv, wbn) - icf_term(ov, wbo);
               dp += icp_term(Nv, wbn) - icp_term(ov, wbo);
@@ -457,27 +598,32 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
           if (df != 0 || dp != 0) {
             ic.f += df;
             ic.p += dp;
-            IC[(size_t)x * n + b] = ic;
-            if (rb == ROLE_NONE) IC[(size_t)b * n + x] = ic;
+            IC[ic_index(x, b, n)] = ic;
           }
-          if (rb == ROLE_NONE) {
-            // row b is not rescanned: fold the new value into its row maximum
+          atomicMax(&bestF[x], mkkey(ic.f, b));
+          atomicMax(&bestP[x], mkkey(ic.p, b));
+          if (rb != ROLE_NONE) {  // both rows are rebuilt from scratch in this pass
+            atomicMax(&bestF[b], mkkey(ic.f, x));
+            atomicMax(&bestP[b], mkkey(ic.p, x));
+          } else {
+            // row b is not revisited as a whole: fold the new value into its row
+            // maximum; if the maximum sat on this very column and went down, the
+            // stored maximum is now only an upper bound -> mark the row stale
+            const unsigned long long c1 = mkkey(ic.f, x), c2 = mkkey(ic.p, x);
             const unsigned long long k1 = bestF[b], k2 = bestP[b];
-            if ((k1 && key_col(k1) == x) || (k2 && key_col(k2) == x)) dirty[b] = 1;
-            else {
-              const unsigned long long nk1 = mkkey(ic.f, x), nk2 = mkkey(ic.p, x);
-              if (nk1 > k1) bestF[b] = nk1;
-              if (nk2 > k2) bestP[b] = nk2;
-            }
+            if ((k1 && key_col(k1) == x && c1 < k1) || (k2 && key_col(k2) == x && c2 < k2))
+              atomicOr(&stalew[b >> 5], 1u << (b & 31));
+            atomicMax(&bestF[b], c1);
+            atomicMax(&bestP[b], c2);
           }
         }
       }
       __syncthreads();
+      AHK_T(3);
 
-      // ---- P4: rewrite the edges of S, merge the cliques --------------------
+      // ---- P4: rewrite the weights of S, merge the cliques
       {
         const int N1 = merge ? W_PERM : W_FORB;
-        const IcPair dead = {-1, -1};
         for (int xi = 0; xi < nA; xi++) {
           const int x = listA[xi];
           for (int yi = tid; yi < nB + nFb; yi += kBlock) {
@@ -485,8 +631,6 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
             const int N = yi < nB ? N1 : W_FORB;
             Wm[(size_t)x * n + y] = N;
             Wm[(size_t)y * n + x] = N;
-            IC[(size_t)x * n + y] = dead;
-            IC[(size_t)y * n + x] = dead;
           }
         }
         for (int xi = 0; xi < nB; xi++) {
@@ -495,38 +639,23 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
             const int y = listFa[yi];
             Wm[(size_t)x * n + y] = W_FORB;
             Wm[(size_t)y * n + x] = W_FORB;
-            IC[(size_t)x * n + y] = dead;
-            IC[(size_t)y * n + x] = dead;
           }
         }
         if (merge)
           for (int yi = tid; yi < nB; yi += kBlock) cl[listB[yi]] = (unsigned short)cu;
+        if (tid < 4) s_cnt[tid] = 0;
+        if (tid == 0) s_items = 0;
       }
       __syncthreads();
-
-      // ---- P5: rescan the rows of T and the rows flagged dirty --------------
-      for (int r = wv; r < n; r += 4) {
-        if (role[r] == ROLE_NONE && !dirty[r]) continue;  // wave-uniform
-        unsigned long long kF = 0, kP = 0;
-        for (int b = lane; b < n; b += 64) {
-          const IcPair v = IC[(size_t)r * n + b];
-          if (v.f >= 0) {
-            const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
-            kF = k1 > kF ? k1 : kF;
-            kP = k2 > kP ? k2 : kP;
-          }
-        }
-        kF = wave_max_u64(kF);
-        kP = wave_max_u64(kP);
-        if (lane == 0) {
-          bestF[r] = kF;
-          bestP[r] = kP;
-          dirty[r] = 0;
-        }
-      }
-      __syncthreads();
+      AHK_T(4);
     }
     __syncthreads();
+#ifdef AHK_TIMING
+    if (tid == 0 && blockIdx.x == 0)
+      printf("chain %d n=%d iters=%lld retries=%lld rescans=%lld sumT=%lld | cycles P1=%lld resc=%lld P2=%lld P3a=%lld P3b=%lld P4=%lld\n", c, n, iters,
+             nretry, nresc, sumT, tacc[0], tacc[1], tacc[2], tacc[5], tacc[3], tacc[4]);
+#endif
+    if (lds.stop_after == 3) continue;
 
     // ---- clusters: ordered by smallest member ------------------------------
     // (bestF is free now: reuse as scratch)
@@ -770,9 +899,11 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
 }
 
 size_t phase_lds_bytes(const PhaseLds& l) {
-  size_t b = (size_t)l.nmax * 8 * 2;  // bestF, bestP
-  b += (size_t)l.nmax * 2 * 5;        // cl + 4 lists
-  b += (size_t)l.nmax * 2;            // role, dirty
+  size_t b = (size_t)l.nmax * 8 * 2;       // bestF, bestP
+  b += (size_t)l.nmax * 2 * 5;             // cl + 4 lists
+  b += (size_t)l.nmax * 2 * 5;             // rowbuf[4], dlist
+  b += (size_t)((l.nmax + 31) / 32) * 4;   // stalew
+  b += (size_t)l.nmax;                     // role
   return (b + 15) & ~(size_t)15;
 }
 

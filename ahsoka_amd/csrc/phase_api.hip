@@ -304,6 +304,8 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   h->pl.nmax = std::min(maxG, kMaxReads);
   // 16-byte friendly capacity
   h->pl.nmax = (h->pl.nmax + 7) & ~7;
+  h->pl.stop_after = 0;
+  if (const char* sa = std::getenv("AHSOKA_STOP_AFTER")) h->pl.stop_after = std::atoi(sa);  // profiling aid
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, prm->device) != hipSuccess) return fail(AHSOKA_E_NODEVICE);
   if (readset_lds_bytes(h->rl) > (size_t)prop.sharedMemPerBlock || phase_lds_bytes(h->pl) > (size_t)prop.sharedMemPerBlock)
@@ -321,7 +323,7 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   {
     size_t freeb = 0, totalb = 0;
     if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) return fail(AHSOKA_E_HIP);
-    const double per_slot = (double)ws.nmax * ws.nmax * 20.0 + (double)ws.Pmax * ws.Tmax * 14.0 + 1e5;
+    const double per_slot = (double)ws.nmax * ws.nmax * 24.2 + (double)ws.Pmax * ws.Tmax * 14.0 + 1e5;
     const long long fit = (long long)((double)freeb * 0.6 / per_slot);
     if (fit < 1) return fail(AHSOKA_E_NOMEM);
     if (slots > fit) slots = (int)fit;
@@ -330,6 +332,8 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   const size_t S = (size_t)slots;
   if ((rc = h->dalloc(&ws.W, S * ws.nmax * ws.nmax))) return fail(rc);
   if ((rc = h->dalloc(&ws.IC, S * ws.nmax * ws.nmax))) return fail(rc);
+  if ((rc = h->dalloc(&ws.live, S * ws.nmax * ((ws.nmax + 63) / 64)))) return fail(rc);
+  if ((rc = h->dalloc(&ws.items, S * ws.nmax * ws.nmax))) return fail(rc);
   if ((rc = h->dalloc(&ws.rates, S * 2 * ws.nmax))) return fail(rc);
   if ((rc = h->dalloc(&ws.tp_k, S * ws.Pmax))) return fail(rc);
   if ((rc = h->dalloc(&ws.tp_gcid, S * ws.Pmax * 8))) return fail(rc);

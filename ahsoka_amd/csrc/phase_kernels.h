@@ -78,6 +78,8 @@ struct DeviceBatch {
 struct SlotWorkspace {
   int* W;               // [slots][nmax*nmax]
   IcPair* IC;           // [slots][nmax*nmax]
+  unsigned long long* live;  // [slots][nmax*ceil(nmax/64)] live-edge bitmap rows
+  unsigned int* items;       // [slots][nmax*nmax] overflow of the per-iteration edge list
   double* rates;        // [slots][2*nmax]   same_i, diff_i
   // threading tables
   int* tp_k;            // [slots][Pmax]         clusters per position
@@ -105,7 +107,8 @@ struct ReadsetLds {
   int maxB;
 };
 struct PhaseLds {
-  int nmax;  // capacity of the per-read LDS arrays
+  int nmax;        // capacity of the per-read LDS arrays
+  int stop_after;  // 0 = run everything; 2/3: profiling aid, stop after S5 init / S5 loop
 };
 size_t readset_lds_bytes(const ReadsetLds& l);
 void launch_readset(const DeviceBatch& db, int C, const ReadsetLds& l, hipStream_t stream);
