@@ -48,18 +48,19 @@
 
 namespace ahk {
 
-constexpr long long BIGV = 1ll << 40;
 constexpr int ROLE_NONE = 0, ROLE_A = 1, ROLE_B = 2, ROLE_FA = 3, ROLE_FB = 4;
 
-__device__ __forceinline__ long long wval(int w) {
-  return w == W_PERM ? BIGV : (w == W_FORB ? -BIGV : (long long)w);
-}
-__device__ __forceinline__ long long icf_term(long long p, long long q) {
+// Triangle terms in 32-bit: W_PERM = INT_MAX and W_FORB = -INT_MAX act as +-infinity
+// under min/negation.  (A term with BOTH edges infinite never reaches a live
+// edge: the third edge of such a triangle is already implied.)
+__device__ __forceinline__ int wval(int w) { return w; }
+__device__ __forceinline__ int icf_term(int p, int q) {
   return (p > 0 && q > 0) ? (p < q ? p : q) : 0;
 }
-__device__ __forceinline__ long long icp_term(long long p, long long q) {
-  if (p < 0 && q > 0) return q < -p ? q : -p;
-  if (p > 0 && q < 0) return -q < p ? -q : p;
+__device__ __forceinline__ int icp_term(int p, int q) {
+  const int np = -p, nq = -q;
+  if (p < 0 && q > 0) return q < np ? q : np;
+  if (p > 0 && q < 0) return nq < p ? nq : p;
   return 0;
 }
 // packed row-best key: larger value wins, then the smaller column
@@ -88,18 +89,17 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return v;
 }
 
-// is the pair (role r1, role r2) rewritten by this iteration, and to what
+// is the pair (role r1, role r2) rewritten by this iteration, and to what:
+// bit (r1*5 + r2) of a 25-bit table
+constexpr unsigned int pair_bit(int r1, int r2) { return 1u << (r1 * 5 + r2); }
+constexpr unsigned int kPairAB = pair_bit(ROLE_A, ROLE_B) | pair_bit(ROLE_B, ROLE_A);
+constexpr unsigned int kPairMerge = kPairAB | pair_bit(ROLE_B, ROLE_FA) | pair_bit(ROLE_FA, ROLE_B) |
+                                    pair_bit(ROLE_A, ROLE_FB) | pair_bit(ROLE_FB, ROLE_A);
 __device__ __forceinline__ bool in_s(int r1, int r2, bool merge) {
-  if (r1 == ROLE_NONE || r2 == ROLE_NONE) return false;
-  if ((r1 == ROLE_A && r2 == ROLE_B) || (r1 == ROLE_B && r2 == ROLE_A)) return true;
-  if (!merge) return false;
-  if ((r1 == ROLE_B && r2 == ROLE_FA) || (r1 == ROLE_FA && r2 == ROLE_B)) return true;
-  if ((r1 == ROLE_A && r2 == ROLE_FB) || (r1 == ROLE_FB && r2 == ROLE_A)) return true;
-  return false;
+  return ((merge ? kPairMerge : kPairAB) >> (r1 * 5 + r2)) & 1u;
 }
 __device__ __forceinline__ int new_w(int r1, int r2, bool merge) {
-  const bool ab = (r1 == ROLE_A && r2 == ROLE_B) || (r1 == ROLE_B && r2 == ROLE_A);
-  return (ab && merge) ? W_PERM : W_FORB;
+  return (merge && ((kPairAB >> (r1 * 5 + r2)) & 1u)) ? W_PERM : W_FORB;
 }
 
 
@@ -134,7 +134,7 @@ __device__ __forceinline__ void pair_overlap(const ChainCtx& cx, int i, int j, i
   *d_out = d;
 }
 
-__global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
+__global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
                                                   int C, int* __restrict__ qhead) {
   extern __shared__ __align__(16) unsigned long long smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
             long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
             for (int wi = 0; wi < deg; wi++) {
               const int w = nbr[wi];
-              const long long waw = Wm[(size_t)a * n + w];  // wave-uniform
-              const long long wwb = Wm[(size_t)w * n + b];
+              const int waw = Wm[(size_t)a * n + w];  // wave-uniform
+              const int wwb = Wm[(size_t)w * n + b];
               f += icf_term(waw, wwb);
               p += icp_term(waw, wwb);
             }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
     // ================= S5 main loop ========================================
     long long iters = 0;
 #ifdef AHK_TIMING
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)clock64(), nretry = 0, nresc = 0, sumT = 0;
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)clock64(), nretry = 0, nresc = 0, sumT = 0, sumM = 0, sumW = 0;
 #endif
     for (;;) {
       // ---- P1: edge with the largest icf and edge with the largest icp ----
@@ -496,44 +496,60 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
       // ---- P3a: list the surviving live edges (x,b), x in T --------------------
       // One wave per row x: read the row's live bitmap, clear the bits of the
       // edges that die now, append the survivors to a workgroup-wide item list
-      // (first 2*nmax items in LDS, the rest in this slot's HBM scratch).
+      // (first 2*nmax items in LDS, the rest in this slot's HBM scratch).  The
+      // bitmap loads of up to 4 rows per wave are issued before any is used.
       {
         unsigned int* items_lds = (unsigned int*)rowbuf;
         const int cap = 2 * nmax;
-        for (int xi = wv; xi < nT; xi += 4) {
-          int x;
-          if (xi < nA) x = listA[xi];
-          else if (xi < nA + nB) x = listB[xi - nA];
-          else if (xi < nA + nB + nFa) x = listFa[xi - nA - nB];
-          else x = listFb[xi - nA - nB - nFa];
-          const int rx = role[x];
-          const unsigned long long bmw = lane < nw ? LV[(size_t)x * nw + lane] : 0ull;
-          for (int k = 0; k < nw; k++) {
-            const unsigned long long word = __shfl(bmw, k, 64);
-            if (word == 0ull) continue;
-            const int b = (k << 6) + lane;
-            const bool bit = (word >> lane) & 1ull;
-            const int rbk = role[b];
-            const bool dies = bit && in_s(rx, rbk, merge);
-            // an edge with both ends in T is listed once, from its lower end
-            const bool lv = bit && !dies && (rbk == ROLE_NONE || x < b);
-            const unsigned long long dm = __ballot(dies), mk = __ballot(lv);
-            if (dm != 0ull && lane == 0) LV[(size_t)x * nw + k] = word & ~dm;
-            if (mk == 0ull) continue;
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_items, __popcll(mk));
-            base = __shfl(base, 0, 64);
-            if (lv) {
-              const int idx = base + __popcll(mk & ((1ull << lane) - 1ull));
-              const unsigned int it = ((unsigned)x << 16) | (unsigned)b;
-              if (idx < cap) items_lds[idx] = it;
-              else items_glb[idx - cap] = it;
+        for (int xi0 = wv; xi0 < nT; xi0 += 4 * 4) {
+          unsigned long long bm[4];
+          int xs[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int xi = xi0 + 4 * j;
+            int x = -1;
+            if (xi < nT) {
+              if (xi < nA) x = listA[xi];
+              else if (xi < nA + nB) x = listB[xi - nA];
+              else if (xi < nA + nB + nFa) x = listFa[xi - nA - nB];
+              else x = listFb[xi - nA - nB - nFa];
             }
+            xs[j] = x;
+            bm[j] = (x >= 0 && lane < nw) ? LV[(size_t)x * nw + lane] : 0ull;
           }
-          if (lane == 0) {  // the row maximum of x is rebuilt from scratch in P3b
-            bestF[x] = 0;
-            bestP[x] = 0;
-            atomicAnd(&stalew[x >> 5], ~(1u << (x & 31)));
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int x = xs[j];
+            if (x < 0) continue;
+            const int rx = role[x];
+            const unsigned long long bmw = bm[j];
+            for (int k = 0; k < nw; k++) {
+              const unsigned long long word = __shfl(bmw, k, 64);
+              if (word == 0ull) continue;
+              const int b = (k << 6) + lane;
+              const bool bit = (word >> lane) & 1ull;
+              const int rbk = role[b];
+              const bool dies = bit && in_s(rx, rbk, merge);
+              // an edge with both ends in T is listed once, from its lower end
+              const bool lv = bit && !dies && (rbk == ROLE_NONE || x < b);
+              const unsigned long long dm = __ballot(dies), mk = __ballot(lv);
+              if (dm != 0ull && lane == 0) LV[(size_t)x * nw + k] = word & ~dm;
+              if (mk == 0ull) continue;
+              int base = 0;
+              if (lane == 0) base = atomicAdd(&s_items, __popcll(mk));
+              base = __shfl(base, 0, 64);
+              if (lv) {
+                const int idx = base + __popcll(mk & ((1ull << lane) - 1ull));
+                const unsigned int it = ((unsigned)x << 16) | (unsigned)b;
+                if (idx < cap) items_lds[idx] = it;
+                else items_glb[idx - cap] = it;
+              }
+            }
+            if (lane == 0) {  // the row maximum of x is rebuilt from scratch in P3b
+              bestF[x] = 0;
+              bestP[x] = 0;
+              atomicAnd(&stalew[x >> 5], ~(1u << (x & 31)));
+            }
           }
         }
       }
@@ -541,80 +557,111 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
       AHK_T(5);
 
       // ---- P3b: one lane per listed edge: apply this iteration's changes --------
+      // Each lane takes up to 4 edges per pass and issues all of their first
+      // loads (the edge's induced costs and the first rewritten triangle) before
+      // it consumes any: the pass costs one HBM round trip instead of four.
       {
         const unsigned int* items_lds = (const unsigned int*)rowbuf;
         const int cap = 2 * nmax;
         const int M = s_items;
-        for (int i = tid; i < M; i += kBlock) {
-          const unsigned int it = i < cap ? items_lds[i] : items_glb[i - cap];
-          const int x = (int)(it >> 16), b = (int)(it & 0xffffu);
-          const int rx = role[x], rb = role[b];
-          IcPair ic = IC[ic_index(x, b, n)];
-          // columns rewritten in row x: two lists, each with its new weight
-          const unsigned short* L1 = nullptr; int n1 = 0, N1 = 0;
-          const unsigned short* L2 = nullptr; int n2 = 0;
-          if (rx == ROLE_A) { L1 = listB; n1 = nB; N1 = merge ? W_PERM : W_FORB; L2 = listFb; n2 = nFb; }
-          else if (rx == ROLE_B) { L1 = listA; n1 = nA; N1 = merge ? W_PERM : W_FORB; L2 = listFa; n2 = nFa; }
-          else if (rx == ROLE_FA) { L1 = listB; n1 = nB; N1 = W_FORB; }
-          else { L1 = listA; n1 = nA; N1 = W_FORB; }
-          long long df = 0, dp = 0;
-          for (int pass = 0; pass < 2; pass++) {
-            const unsigned short* L = pass == 0 ? L1 : L2;
-            const int nl = pass == 0 ? n1 : n2;
-            const long long Nv = wval(pass == 0 ? N1 : W_FORB);
-#pragma unroll 4
-            for (int wi = 0; wi < nl; wi++) {
-              const int w = L[wi];
-              const long long ov = wval(Wm[(size_t)x * n + w]);
-              const long long wbo = wval(Wm[(size_t)w * n + b]);
-              const int rw = role[w];
-              const long long wbn = in_s(rw, rb, merge) ? wval(new_w(rw, rb, merge)) : wbo;
-              df += icf_term(Nv, wbn) - icf_term(ov, wbo);
-              dp += icp_term(Nv, wbn) - icp_term(ov, wbo);
+#ifdef AHK_TIMING
+        sumM += M;
+#endif
+        constexpr int UN = 1;
+        for (int base = tid; base < M; base += kBlock * UN) {
+          int xs[UN], bs[UN], w0s[UN], a0s[UN], c0s[UN];
+          IcPair ics[UN];
+#pragma unroll
+          for (int j = 0; j < UN; j++) {
+            const int i = base + j * kBlock;
+            xs[j] = -1;
+            if (i < M) {
+              const unsigned int it = i < cap ? items_lds[i] : items_glb[i - cap];
+              const int x = (int)(it >> 16), b = (int)(it & 0xffffu);
+              const int rx = role[x];
+              // first rewritten column of row x (its list is never empty)
+              const int w0 = (rx == ROLE_A || rx == ROLE_FA) ? listB[0] : listA[0];
+              xs[j] = x;
+              bs[j] = b;
+              w0s[j] = w0;
+              ics[j] = IC[ic_index(x, b, n)];
+              a0s[j] = Wm[(size_t)x * n + w0];
+              c0s[j] = Wm[(size_t)w0 * n + b];
             }
           }
-          if (rb != ROLE_NONE) {
-            // triangles whose changed edge is (b,w) only: w in C(b) \ C(x)
-            const unsigned short* M1 = nullptr; int m1 = 0, Q1 = 0;
-            const unsigned short* M2 = nullptr; int m2 = 0;
-            if (rb == ROLE_A) { M1 = listB; m1 = nB; Q1 = merge ? W_PERM : W_FORB; M2 = listFb; m2 = nFb; }
-            else if (rb == ROLE_B) { M1 = listA; m1 = nA; Q1 = merge ? W_PERM : W_FORB; M2 = listFa; m2 = nFa; }
-            else if (rb == ROLE_FA) { M1 = listB; m1 = nB; Q1 = W_FORB; }
-            else { M1 = listA; m1 = nA; Q1 = W_FORB; }
+#pragma unroll
+          for (int j = 0; j < UN; j++) {
+            const int x = xs[j];
+            if (x < 0) continue;
+            const int b = bs[j];
+            const int rx = role[x], rb = role[b];
+            IcPair ic = ics[j];
+            // columns rewritten in row x: two lists, each with its new weight
+            const unsigned short* L1 = nullptr; int n1 = 0, N1 = 0;
+            const unsigned short* L2 = nullptr; int n2 = 0;
+            if (rx == ROLE_A) { L1 = listB; n1 = nB; N1 = merge ? W_PERM : W_FORB; L2 = listFb; n2 = nFb; }
+            else if (rx == ROLE_B) { L1 = listA; n1 = nA; N1 = merge ? W_PERM : W_FORB; L2 = listFa; n2 = nFa; }
+            else if (rx == ROLE_FA) { L1 = listB; n1 = nB; N1 = W_FORB; }
+            else { L1 = listA; n1 = nA; N1 = W_FORB; }
+            long long df = 0, dp = 0;
             for (int pass = 0; pass < 2; pass++) {
-              const unsigned short* L = pass == 0 ? M1 : M2;
-              const int nl = pass == 0 ? m1 : m2;
-              const long long Nv = wval(pass == 0 ? Q1 : W_FORB);
+              const unsigned short* L = pass == 0 ? L1 : L2;
+              const int nl = pass == 0 ? n1 : n2;
+              const int Nv = wval(pass == 0 ? N1 : W_FORB);
               for (int wi = 0; wi < nl; wi++) {
                 const int w = L[wi];
-                if (w == x || in_s(rx, role[w], merge)) continue;  // (x,w) changes too: counted above
-                const long long ov = wval(Wm[(size_t)w * n + b]);
-                const long long xw = wval(Wm[(size_t)x * n + w]);
-                df += icf_term(Nv, xw) - icf_term(ov, xw);
-                dp += icp_term(Nv, xw) - icp_term(ov, xw);
+                const bool pre = pass == 0 && wi == 0;  // L1[0] == w0: already loaded
+                const int ov = wval(pre ? a0s[j] : Wm[(size_t)x * n + w]);
+                const int wbo = wval(pre ? c0s[j] : Wm[(size_t)w * n + b]);
+                const int rw = role[w];
+                const int wbn = in_s(rw, rb, merge) ? wval(new_w(rw, rb, merge)) : wbo;
+                df += icf_term(Nv, wbn) - icf_term(ov, wbo);
+                dp += icp_term(Nv, wbn) - icp_term(ov, wbo);
               }
             }
-          }
-          if (df != 0 || dp != 0) {
-            ic.f += df;
-            ic.p += dp;
-            IC[ic_index(x, b, n)] = ic;
-          }
-          atomicMax(&bestF[x], mkkey(ic.f, b));
-          atomicMax(&bestP[x], mkkey(ic.p, b));
-          if (rb != ROLE_NONE) {  // both rows are rebuilt from scratch in this pass
-            atomicMax(&bestF[b], mkkey(ic.f, x));
-            atomicMax(&bestP[b], mkkey(ic.p, x));
-          } else {
-            // row b is not revisited as a whole: fold the new value into its row
-            // maximum; if the maximum sat on this very column and went down, the
-            // stored maximum is now only an upper bound -> mark the row stale
-            const unsigned long long c1 = mkkey(ic.f, x), c2 = mkkey(ic.p, x);
-            const unsigned long long k1 = bestF[b], k2 = bestP[b];
-            if ((k1 && key_col(k1) == x && c1 < k1) || (k2 && key_col(k2) == x && c2 < k2))
-              atomicOr(&stalew[b >> 5], 1u << (b & 31));
-            atomicMax(&bestF[b], c1);
-            atomicMax(&bestP[b], c2);
+            if (rb != ROLE_NONE) {
+              // triangles whose changed edge is (b,w) only: w in C(b) \ C(x)
+              const unsigned short* M1 = nullptr; int m1 = 0, Q1 = 0;
+              const unsigned short* M2 = nullptr; int m2 = 0;
+              if (rb == ROLE_A) { M1 = listB; m1 = nB; Q1 = merge ? W_PERM : W_FORB; M2 = listFb; m2 = nFb; }
+              else if (rb == ROLE_B) { M1 = listA; m1 = nA; Q1 = merge ? W_PERM : W_FORB; M2 = listFa; m2 = nFa; }
+              else if (rb == ROLE_FA) { M1 = listB; m1 = nB; Q1 = W_FORB; }
+              else { M1 = listA; m1 = nA; Q1 = W_FORB; }
+              for (int pass = 0; pass < 2; pass++) {
+                const unsigned short* L = pass == 0 ? M1 : M2;
+                const int nl = pass == 0 ? m1 : m2;
+                const int Nv = wval(pass == 0 ? Q1 : W_FORB);
+                for (int wi = 0; wi < nl; wi++) {
+                  const int w = L[wi];
+                  if (w == x || in_s(rx, role[w], merge)) continue;  // (x,w) changes too: counted above
+                  const int ov = wval(Wm[(size_t)w * n + b]);
+                  const int xw = wval(Wm[(size_t)x * n + w]);
+                  df += icf_term(Nv, xw) - icf_term(ov, xw);
+                  dp += icp_term(Nv, xw) - icp_term(ov, xw);
+                }
+              }
+            }
+            if (df != 0 || dp != 0) {
+              ic.f += df;
+              ic.p += dp;
+              IC[ic_index(x, b, n)] = ic;
+            }
+            atomicMax(&bestF[x], mkkey(ic.f, b));
+            atomicMax(&bestP[x], mkkey(ic.p, b));
+            if (rb != ROLE_NONE) {  // both rows are rebuilt from scratch in this pass
+              atomicMax(&bestF[b], mkkey(ic.f, x));
+              atomicMax(&bestP[b], mkkey(ic.p, x));
+            } else {
+              // row b is not revisited as a whole: fold the new value into its row
+              // maximum; if the maximum sat on this very column and went down, the
+              // stored maximum is now only an upper bound -> mark the row stale
+              const unsigned long long c1 = mkkey(ic.f, x), c2 = mkkey(ic.p, x);
+              const unsigned long long k1 = bestF[b], k2 = bestP[b];
+              if ((k1 && key_col(k1) == x && c1 < k1) || (k2 && key_col(k2) == x && c2 < k2))
+                atomicOr(&stalew[b >> 5], 1u << (b & 31));
+              atomicMax(&bestF[b], c1);
+              atomicMax(&bestP[b], c2);
+            }
           }
         }
       }
@@ -652,8 +699,8 @@ __global__ __launch_bounds__(kBlock) void k_phase(DeviceBatch db, SlotWorkspace 
     __syncthreads();
 #ifdef AHK_TIMING
     if (tid == 0 && blockIdx.x == 0)
-      printf("chain %d n=%d iters=%lld retries=%lld rescans=%lld sumT=%lld | cycles P1=%lld resc=%lld P2=%lld P3a=%lld P3b=%lld P4=%lld\n", c, n, iters,
-             nretry, nresc, sumT, tacc[0], tacc[1], tacc[2], tacc[5], tacc[3], tacc[4]);
+      printf("chain %d n=%d iters=%lld retries=%lld rescans=%lld sumT=%lld sumM=%lld sumW=%lld | cycles P1=%lld resc=%lld P2=%lld P3a=%lld P3b=%lld P4=%lld\n", c, n, iters,
+             nretry, nresc, sumT, sumM, sumW, tacc[0], tacc[1], tacc[2], tacc[5], tacc[3], tacc[4]);
 #endif
     if (lds.stop_after == 3) continue;
 

@@ -15,7 +15,7 @@ constexpr int kMaxPloidy = 4;       // tuples = (2p)^p <= 4096
 constexpr int kBlock = 256;         // threads per workgroup (4 wavefronts)
 
 constexpr int32_t W_PERM = 0x7fffffff;
-constexpr int32_t W_FORB = (int32_t)0x80000000;
+constexpr int32_t W_FORB = -0x7fffffff;  // -INT_MAX: its negation is W_PERM
 
 struct alignas(16) IcPair {  // induced cost of forbidding / of making permanent
   long long f, p;

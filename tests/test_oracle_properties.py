@@ -1,0 +1,74 @@
+"""Properties of the oracle itself (CPU only): the incremental induced-cost
+bookkeeping equals recomputation from the definition; the deterministic log is
+the same function in the oracle and in the product header and agrees with
+libm; clean synthetic data is phased back to its truth; threads do not change
+results."""
+import math
+
+import numpy as np
+import pytest
+
+from ahsoka_amd import capi
+import oracle_binding as ob
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_incremental_cluster_editing_equals_bruteforce(seed):
+    b = capi.synth_batch(n_chains=3, n_bubbles=8, n_reads=60, seed=seed, allele_err=0.08)
+    prm = capi.default_params(want_stages=1)
+    fast = ob.phase_batch(b, prm)
+    slow = ob.phase_batch(b, prm, brute_ce=True)
+    np.testing.assert_array_equal(fast.stages["fread_cluster"], slow.stages["fread_cluster"])
+    np.testing.assert_array_equal(fast.n_iterations, slow.n_iterations)
+    np.testing.assert_array_equal(fast.hap_allele, slow.hap_allele)
+
+
+def test_det_log_matches_libm_and_product():
+    xs = np.concatenate([np.linspace(0.001, 0.999, 997), [0.5, 0.25, 1.0, 0.7071067811865476, 1.4142135623730951, 3.0, 1e-3]])
+    for x in xs:
+        a = ob.lib().oracle_det_log(float(x))
+        b = capi.lib().ahsoka_test_detlog(float(x))
+        assert a == b, x  # bit-identical: same operations in the same order
+        assert abs(a - math.log(x)) <= 4e-16 * max(1.0, abs(math.log(x))), x
+
+
+def test_clean_data_is_phased_to_truth():
+    """no allele errors: the two haplotypes must be complementary and constant
+    along every chain up to the unavoidable global swap"""
+    b = capi.synth_batch(n_chains=6, n_bubbles=12, n_reads=150, seed=123, allele_err=0.0)
+    r = ob.phase_batch(b)
+    assert (r.status == capi.ST_PHASED).all()
+    for c in range(6):
+        h = r.chain_haps(c)
+        assert ((h[0] ^ h[1]) == 1).all()
+        assert (r.n_clusters[c] == 2)
+
+
+def test_threads_do_not_change_results():
+    b = capi.synth_batch(n_chains=9, n_bubbles=10, n_reads=80, seed=8)
+    r1 = ob.phase_batch(b, n_threads=1)
+    r4 = ob.phase_batch(b, n_threads=4)
+    np.testing.assert_array_equal(r1.hap_allele, r4.hap_allele)
+    np.testing.assert_array_equal(r1.n_iterations, r4.n_iterations)
+
+
+def test_duplicate_read_names_merge_into_one_read():
+    """two GAF lines with the same name are one Read for ReadSet::getByName
+    (src/alignmentstoreadset.cpp:116): the final readset has one entry for it"""
+    b = capi.synth_batch(n_chains=1, n_bubbles=6, n_reads=30, seed=3)
+    a = b.arrays()
+    names = a["read_name"].copy()
+    names[1] = names[0]  # alignment 1 now carries the name of alignment 0
+    # keep name ids dense in first-appearance order
+    remap, nxt = {}, 0
+    for i, v in enumerate(names):
+        if v not in remap:
+            remap[v] = nxt
+            nxt += 1
+        names[i] = remap[v]
+    a["read_name"] = names
+    nb = capi.ChainBatch(arrays={k: v for k, v in a.items() if v is not None})
+    r = ob.phase_batch(nb, capi.default_params(want_stages=1))
+    fn = r.stages["fread_name"]
+    assert len(set(fn.tolist())) == len(fn)
+    assert r.n_reads[0] <= 29

@@ -1,0 +1,95 @@
+"""The N > 1 path on CPU: world_size 2, gloo.  Each rank takes its block of one
+global synthetic workload (the generator is seeded per chain, so a rank builds
+exactly its shard), 'phases' it -- here with the CPU oracle standing in for the
+GPU, which is what tests may do -- and the single gather to rank 0 must
+reproduce the one-process result chain for chain, in global order."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, cfg, q):
+    import torch.distributed as dist
+
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ahsoka_amd import capi, shard
+    import oracle_binding as ob
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = cfg["n_chains"]
+    first, count = shard.block_partition(total, world)[rank]
+    mine = dict(cfg)
+    mine["n_chains"] = count
+    mine["first_chain"] = first
+    b = capi.synth_batch(**mine)
+    res = ob.phase_batch(b, capi.default_params(ploidy=cfg["ploidy"]))
+    owned = np.arange(first, first + count)
+    got = shard.gather_to_rank0(res, owned, total, cfg["n_bubbles"])
+    if rank == 0:
+        q.put(tuple(np.asarray(x) for x in got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [7, 10])
+def test_two_ranks_equal_one_process(total):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ahsoka_amd import capi
+    import oracle_binding as ob
+
+    cfg = dict(n_chains=total, n_bubbles=6, n_reads=60, ploidy=2, seed=77)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + total
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    status, pos_off, pos, hap = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = ob.phase_batch(capi.synth_batch(**cfg), capi.default_params())
+    np.testing.assert_array_equal(status, ref.status)
+    np.testing.assert_array_equal(pos_off, ref.pos_off)
+    np.testing.assert_array_equal(pos, ref.pos)
+    np.testing.assert_array_equal(hap, ref.hap_allele)
+
+
+def test_partitions():
+    from ahsoka_amd import shard
+
+    assert shard.block_partition(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    assert shard.block_partition(3, 8)[-1] == (3, 0)
+    costs = [100, 1, 1, 1, 50, 50, 2, 2]
+    parts = shard.lpt_partition(costs, 2)
+    assert sorted(np.concatenate(parts).tolist()) == list(range(8))
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert abs(loads[0] - loads[1]) <= 7
+    # deterministic
+    assert all((a == b).all() for a, b in zip(parts, shard.lpt_partition(costs, 2)))
+
+
+def test_pack_unpack_roundtrip():
+    from ahsoka_amd import capi, shard
+    import oracle_binding as ob
+
+    b = capi.synth_batch(n_chains=5, n_bubbles=9, n_reads=40, seed=5)
+    r = ob.phase_batch(b)
+    rec = shard.pack_records(r, 8, 9)
+    assert rec.shape == (8, 2 + 9 + 2 * 9) and (rec[5:, 0] == -1).all()
+    status, pos_off, pos, hap = shard.unpack_records(rec, 2, 9)
+    np.testing.assert_array_equal(status, r.status)
+    np.testing.assert_array_equal(pos_off, r.pos_off)
+    np.testing.assert_array_equal(pos, r.pos)
+    np.testing.assert_array_equal(hap, r.hap_allele)
