@@ -112,3 +112,108 @@ def test_render_matches_haplotypes():
     # chain 0: nodes 1..16, bubble k -> source 3k+1, inner 3k+2+allele
     exp = "".join(f"{3 * k + 1}(+),{3 * k + 2 + int(hap[0][j])}(+)," for j, k in enumerate(g.chain_pos(0)))
     assert lines[3] == exp
+
+
+def _dense_names(names):
+    remap, out = {}, names.copy()
+    for i, v in enumerate(names):
+        out[i] = remap.setdefault(int(v), len(remap))
+    return out
+
+
+def test_duplicate_read_names():
+    """several alignments with one name are one Read (getByName,
+    src/alignmentstoreadset.cpp:116,233): the kernel's per-name merge path"""
+    b = capi.synth_batch(n_chains=3, n_bubbles=10, n_reads=90, seed=21)
+    a = b.arrays()
+    names = a["read_name"].copy()
+    rng = np.random.default_rng(5)
+    for c in range(3):
+        r0, r1 = a["read_off"][c], a["read_off"][c + 1]
+        for _ in range(25):
+            i, j = rng.integers(r0, r1, size=2)
+            names[max(i, j)] = names[min(i, j)]
+        names[r0:r1] = _dense_names(names[r0:r1])
+    a["read_name"] = names
+    nb = capi.ChainBatch(arrays={k: v for k, v in a.items() if v is not None})
+    g, o = _compare(nb, capi.default_params(want_stages=1))
+    assert (g.n_reads < 90).all()
+
+
+def test_reads_with_foreign_nodes_and_empty_middle():
+    """toy fixture through the ingest: indel bubble (2-node allele path: empty
+    middle matches every alignment, quirk Q6), 3-inner-node bubble, reads that
+    leave the chain (-1 nodes), a repeated read name"""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    b = capi.ingest(os.path.join(gold, "toy.gfa"), os.path.join(gold, "toy.gaf"))
+    _compare(b, capi.default_params(want_stages=1, min_mapq=90))
+    _compare(b, capi.default_params(want_stages=1))
+
+
+def test_c1_text_roundtrip_through_ingest():
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    b = capi.ingest(os.path.join(gold, "c1.gfa"), os.path.join(gold, "c1.gaf"))
+    g, _ = _compare(b, capi.default_params(want_stages=1))
+    assert (g.status == capi.ST_PHASED).all()
+    txt = capi.render_chain(b, g, 0)
+    assert txt.startswith("chain id: 9\nsize of chain: 5\nhaplotype 0:\n")
+
+
+def test_c2_full_vs_oracle():
+    """BASELINE configs[1] at full size: 1000 chains x 20 bubbles x 500 reads."""
+    b = capi.synth_batch(**capi.CONFIGS["c2"])
+    g, _ = _compare(b, capi.default_params(), stages=False, n_threads=16)
+    assert (g.status == capi.ST_PHASED).all()
+
+
+def test_c4_shape_two_chains():
+    """BASELINE configs[3] shape: ploidy 4, 30 bubbles, 2000 reads/chain."""
+    cfg = dict(capi.CONFIGS["c4"])
+    cfg["n_chains"] = 2
+    b = capi.synth_batch(**cfg)
+    _compare(b, capi.default_params(ploidy=4), stages=False, n_threads=2)
+
+
+def test_c5_skewed_sample():
+    """BASELINE configs[4] shape: power-law bubble counts (1..500), includes
+    1-bubble chains (SKIPPED) and multi-word position masks."""
+    cfg = dict(capi.CONFIGS["c5"])
+    cfg["n_chains"] = 400
+    b = capi.synth_batch(**cfg)
+    g, _ = _compare(b, capi.default_params(), stages=False, n_threads=16)
+    assert (g.status == capi.ST_SKIPPED_LE1).sum() > 50
+    assert np.diff(b.arrays()["bubble_off"]).max() > 64
+
+
+def test_c3_full_size_properties():
+    """BASELINE configs[2] at FULL size (10k chains x 50 bubbles x 1000 reads):
+    size-independent properties of a diploid phasing, plus bit-exact parity with
+    the oracle on a sample of the same chains."""
+    cfg = dict(capi.CONFIGS["c3"])
+    b = capi.synth_batch(**cfg)
+    dev = capi.DeviceBatch(b, capi.default_params())
+    dev.phase()
+    g = dev.download()
+    dev.phase()                      # idempotence: the same call gives the same bits
+    g2 = dev.download()
+    dev.free()
+    np.testing.assert_array_equal(g.hap_allele, g2.hap_allele)
+    np.testing.assert_array_equal(g.n_iterations, g2.n_iterations)
+    assert (g.status == capi.ST_PHASED).all()
+    P = np.diff(g.pos_off)
+    assert P.min() >= 45 and P.max() == 50
+    # genotype {0:1,1:1} at every position: the two haplotypes are complementary
+    for c in range(0, 10000, 97):
+        h = g.chain_haps(c)
+        assert ((h[0] ^ h[1]) == 1).all()
+    # oracle on every 400th chain (25 chains), bit-exact
+    idx = list(range(0, 10000, 400))
+    for c in idx:
+        sub = dict(cfg)
+        sub["n_chains"] = 1
+        sub["first_chain"] = c
+        o = ob.phase_batch(capi.synth_batch(**sub), capi.default_params())
+        np.testing.assert_array_equal(o.chain_haps(0), g.chain_haps(c))
+        assert o.n_iterations[0] == g.n_iterations[c]
