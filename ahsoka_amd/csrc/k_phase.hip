@@ -151,6 +151,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
   unsigned int* stalew = (unsigned int*)(dlist + nmax);   // [nmax/32] bit per row: already in dlist
   unsigned char* role = (unsigned char*)(stalew + (nmax + 31) / 32);  // [nmax]
   __shared__ int s_chain, s_cnt[4], s_nd, s_items;
+#ifdef AHK_TIMING
+  __shared__ int s_chg;
+#endif
   __shared__ long long s_rv[16];
   __shared__ unsigned int s_rab[8];
   __shared__ int s_asc[4][8];
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
     // ================= S5 main loop ========================================
     long long iters = 0;
 #ifdef AHK_TIMING
+    if (tid == 0) s_chg = 0;
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)clock64(), nretry = 0, nresc = 0, sumT = 0, sumM = 0, sumW = 0;
 #endif
     for (;;) {
@@ -645,6 +649,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
               ic.f += df;
               ic.p += dp;
               IC[ic_index(x, b, n)] = ic;
+#ifdef AHK_TIMING
+              atomicAdd(&s_chg, 1);
+#endif
             }
             atomicMax(&bestF[x], mkkey(ic.f, b));
             atomicMax(&bestP[x], mkkey(ic.p, b));
@@ -700,7 +707,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
 #ifdef AHK_TIMING
     if (tid == 0 && blockIdx.x == 0)
       printf("chain %d n=%d iters=%lld retries=%lld rescans=%lld sumT=%lld sumM=%lld sumW=%lld | cycles P1=%lld resc=%lld P2=%lld P3a=%lld P3b=%lld P4=%lld\n", c, n, iters,
-             nretry, nresc, sumT, sumM, sumW, tacc[0], tacc[1], tacc[2], tacc[5], tacc[3], tacc[4]);
+             nretry, nresc, sumT, sumM, (long long)s_chg, tacc[0], tacc[1], tacc[2], tacc[5], tacc[3], tacc[4]);
 #endif
     if (lds.stop_after == 3) continue;
 
