@@ -70,6 +70,17 @@ __device__ __forceinline__ unsigned long long mkkey(long long val, int col) {
 __device__ __forceinline__ int key_col(unsigned long long k) { return 4095 - (int)(k & 4095ull); }
 __device__ __forceinline__ long long key_val(unsigned long long k) { return (long long)(k >> 12) - 1; }
 
+// value of a 64-bit register in lane l, l wave-uniform (v_readlane, no LDS crossbar)
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// number of set bits of a wave-uniform mask below this lane
+__device__ __forceinline__ int mask_rank(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
+
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -80,13 +91,24 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// max over the 64 lanes, result in every lane.  DPP row shifts / row broadcasts
+// run in the VALU (a few cycles each); __shfl_xor would go through the LDS
+// crossbar (ds_bpermute, ~100 cycles a step).  0 is the identity.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)v, CTRL, ROWMASK, 0xf, false);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(v >> 32), CTRL, ROWMASK, 0xf, false);
+  const unsigned long long t = ((unsigned long long)hi << 32) | lo;
+  return t > v ? t : v;
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long t = __shfl_xor(v, o, 64);
-    v = t > v ? t : v;
-  }
-  return v;
+  v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_max_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_max_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_max_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row maximum
+  v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
+  return readlane_u64(v, 63);
 }
 
 // is the pair (role r1, role r2) rewritten by this iteration, and to what:
@@ -134,8 +156,13 @@ __device__ __forceinline__ void pair_overlap(const ChainCtx& cx, int i, int j, i
   *d_out = d;
 }
 
+// NOTE: the descriptor structs are passed BY VALUE on purpose: pointers that
+// arrive in the kernarg segment are known to be global, so the compiler emits
+// global_load/global_store.  Read through a pointer-to-struct they degrade to
+// flat_* instructions, which count on lgkmcnt as well -- every LDS wait then
+// also waits for all outstanding HBM traffic (measured: whole-kernel slowdown).
 __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
-                                                  int C, int* __restrict__ qhead) {
+                                                     int C, int* __restrict__ qhead) {
   extern __shared__ __align__(16) unsigned long long smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nmax = lds.nmax;
@@ -149,7 +176,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
   unsigned short* rowbuf = listFb + nmax;                 // [4][nmax] per-wave column buffers
   unsigned short* dlist = rowbuf + 4 * (size_t)nmax;      // [nmax] rows whose maximum must be rescanned
   unsigned int* stalew = (unsigned int*)(dlist + nmax);   // [nmax/32] bit per row: already in dlist
-  unsigned char* role = (unsigned char*)(stalew + (nmax + 31) / 32);  // [nmax]
+  unsigned long long* rmask = (unsigned long long*)(stalew + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][32] role masks per 64-column word
+  unsigned long long* rolenz = rmask + 4 * 32;             // [4][32] OR of the members' nz-rows
+  unsigned char* role = (unsigned char*)(rolenz + 4 * 32);  // [nmax]
   __shared__ int s_chain, s_cnt[4], s_nd, s_items;
 #ifdef AHK_TIMING
   __shared__ int s_chg;
@@ -162,6 +191,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
   int* Wm = ws.W + (size_t)blockIdx.x * ws.nmax * ws.nmax;
   IcPair* IC = ws.IC + (size_t)blockIdx.x * ws.nmax * ws.nmax;
   unsigned long long* LV = ws.live + (size_t)blockIdx.x * ws.nmax * ((ws.nmax + 63) / 64);
+  unsigned long long* NZ = ws.nz + (size_t)blockIdx.x * ws.nmax * ((ws.nmax + 63) / 64);
   unsigned int* items_glb = ws.items + (size_t)blockIdx.x * ws.nmax * ws.nmax;
   double* rates = ws.rates + (size_t)blockIdx.x * 2 * ws.nmax;
   unsigned int* sortbuf = ws.sortbuf + (size_t)blockIdx.x * 4 * ws.nmax;
@@ -304,6 +334,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
     // live-edge bitmap (one u64 per 64 columns): from here on an edge is live
     // iff its bit is set, and IC holds garbage for dead pairs.
     const int nw = (n + 63) >> 6;
+    // words per row rounded up to a power of two (>= 8): lane layout of the row passes
+    const int nwp_log = nw <= 8 ? 3 : nw <= 16 ? 4 : 5;
+    const int nwp = 1 << nwp_log;
+    const int RP = 64 >> nwp_log;  // rows a wave handles at once
     {
       unsigned short* nbr = rowbuf + (size_t)wv * nmax;
       for (int a = wv; a < n; a += 4) {
@@ -314,7 +348,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
           const unsigned long long mk = __ballot(nz);
           if (nz) nbr[deg + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)w;
           deg += __popcll(mk);
-          if (lane == 0) LV[(size_t)a * nw + (w0 >> 6)] = mk;
+          if (lane == 0) {
+            LV[(size_t)a * nw + (w0 >> 6)] = mk;
+            NZ[(size_t)a * nw + (w0 >> 6)] = mk;
+          }
         }
         unsigned long long kF = 0, kP = 0;
         for (int i0 = 0; i0 < deg; i0 += 64) {
@@ -359,7 +396,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
     long long iters = 0;
 #ifdef AHK_TIMING
     if (tid == 0) s_chg = 0;
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)clock64(), nretry = 0, nresc = 0, sumT = 0, sumM = 0, sumW = 0;
+    long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)clock64(), nretry = 0, nresc = 0, sumT = 0, sumM = 0, sumW = 0;
 #endif
     for (;;) {
       // ---- P1: edge with the largest icf and edge with the largest icp ----
@@ -472,98 +509,171 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
       const int ev = merge ? (int)(abf & 0xffff) : (int)(abp & 0xffff);
       const int cu = cl[eu], cv = cl[ev];
 
-      // ---- P2: roles and member lists (s_cnt was zeroed before the last barrier)
-      for (int z = tid; z < n; z += kBlock) {
+      // ---- P2: roles, member lists and per-word role masks --------------------
+      // (s_cnt was zeroed before the last barrier).  rmask[R][k] has bit c set iff
+      // column 64k+c plays role R: the row passes below work on whole 64-column
+      // words with these masks instead of looking at single columns.
+      for (int z0 = 0; z0 < nw * 64; z0 += kBlock) {
+        const int z = z0 + tid;
         int r = ROLE_NONE;
-        const int cz = cl[z];
-        if (cz == cu) r = ROLE_A;
-        else if (cz == cv) r = ROLE_B;
-        else if (merge) {
-          const bool fa = Wm[(size_t)eu * n + z] == W_FORB, fb = Wm[(size_t)ev * n + z] == W_FORB;
-          if (fa && !fb) r = ROLE_FA;
-          if (fb && !fa) r = ROLE_FB;
+        if (z < n) {
+          const int cz = cl[z];
+          if (cz == cu) r = ROLE_A;
+          else if (cz == cv) r = ROLE_B;
+          else if (merge) {
+            const bool fa = Wm[(size_t)eu * n + z] == W_FORB, fb = Wm[(size_t)ev * n + z] == W_FORB;
+            if (fa && !fb) r = ROLE_FA;
+            if (fb && !fa) r = ROLE_FB;
+          }
+          role[z] = (unsigned char)r;
+          if (r == ROLE_A) listA[atomicAdd(&s_cnt[0], 1)] = (unsigned short)z;
+          else if (r == ROLE_B) listB[atomicAdd(&s_cnt[1], 1)] = (unsigned short)z;
+          else if (r == ROLE_FA) listFa[atomicAdd(&s_cnt[2], 1)] = (unsigned short)z;
+          else if (r == ROLE_FB) listFb[atomicAdd(&s_cnt[3], 1)] = (unsigned short)z;
         }
-        role[z] = (unsigned char)r;
-        if (r == ROLE_A) listA[atomicAdd(&s_cnt[0], 1)] = (unsigned short)z;
-        else if (r == ROLE_B) listB[atomicAdd(&s_cnt[1], 1)] = (unsigned short)z;
-        else if (r == ROLE_FA) listFa[atomicAdd(&s_cnt[2], 1)] = (unsigned short)z;
-        else if (r == ROLE_FB) listFb[atomicAdd(&s_cnt[3], 1)] = (unsigned short)z;
+        const unsigned long long m1 = __ballot(r == ROLE_A), m2 = __ballot(r == ROLE_B);
+        const unsigned long long m3 = __ballot(r == ROLE_FA), m4 = __ballot(r == ROLE_FB);
+        const int k = (z0 >> 6) + wv;
+        if (lane == 0 && k < nw) {
+          rmask[0 * 32 + k] = m1;
+          rmask[1 * 32 + k] = m2;
+          rmask[2 * 32 + k] = m3;
+          rmask[3 * 32 + k] = m4;
+        }
       }
       __syncthreads();
       const int nA = s_cnt[0], nB = s_cnt[1], nFa = s_cnt[2], nFb = s_cnt[3];
       const int nT = nA + nB + nFa + nFb;
+      // ---- P2b: per role, the OR of the nz-rows of its members (wave R <-> role R):
+      // "some member w of the role has W[w][b] != 0".  One pass per iteration,
+      // shared by every row of P3a; lists longer than 32 are not filtered.
+      {
+        const unsigned short* Lr = wv == 0 ? listA : wv == 1 ? listB : wv == 2 ? listFa : listFb;
+        const int nr = wv == 0 ? nA : wv == 1 ? nB : wv == 2 ? nFa : nFb;
+        unsigned long long acc = 0ull;
+        if (nr > 32) acc = ~0ull;
+        else if (lane < nw) {
+          for (int w0 = 0; w0 < nr; w0 += 8) {
+            unsigned long long t[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) t[c] = (w0 + c < nr) ? NZ[(size_t)Lr[w0 + c] * nw + lane] : 0ull;
+#pragma unroll
+            for (int c = 0; c < 8; c++) acc |= t[c];
+          }
+        }
+        if (lane < 32) rolenz[wv * 32 + lane] = acc;
+      }
+      __syncthreads();
       AHK_T(2);
 #ifdef AHK_TIMING
       sumT += nT;
 #endif
 
-      // ---- P3a: list the surviving live edges (x,b), x in T --------------------
-      // One wave per row x: read the row's live bitmap, clear the bits of the
-      // edges that die now, append the survivors to a workgroup-wide item list
-      // (first 2*nmax items in LDS, the rest in this slot's HBM scratch).  The
-      // bitmap loads of up to 4 rows per wave are issued before any is used.
+      // ---- P3a: candidate edges (x,b), x in T ----------------------------------
+      // One wave per row x, ONE LANE PER 64-COLUMN WORD.  With D = columns whose
+      // edge to x is rewritten now:   live' = live & ~D   (stored),
+      // nz' = nz | D (stored; nz = "W[x][.] != 0", the third-edge filter),
+      // candidates = live' & (nz-rows of the rewritten columns, OR-ed) -- an edge
+      // (x,b) can only change if some rewritten neighbour w of x has W[w][b] != 0.
+      // Edges inside T are kept unfiltered and listed once, from their lower end.
+      // A row whose stored maximum sits on a dying edge is queued for an exact
+      // rescan in P4; every other row maximum is maintained lazily.
       {
         unsigned int* items_lds = (unsigned int*)rowbuf;
         const int cap = 2 * nmax;
-        for (int xi0 = wv; xi0 < nT; xi0 += 4 * 4) {
-          unsigned long long bm[4];
-          int xs[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int xi = xi0 + 4 * j;
-            int x = -1;
-            if (xi < nT) {
-              if (xi < nA) x = listA[xi];
-              else if (xi < nA + nB) x = listB[xi - nA];
-              else if (xi < nA + nB + nFa) x = listFa[xi - nA - nB];
-              else x = listFb[xi - nA - nB - nFa];
-            }
-            xs[j] = x;
-            bm[j] = (x >= 0 && lane < nw) ? LV[(size_t)x * nw + lane] : 0ull;
+        // Lane layout: a wave works on RP = 64/nwp rows at once, lane = (row slot,
+        // 64-column word), nwp = nw rounded up to a power of two (>= 8).  With
+        // 10 words per row that is 4 rows per wave pass, 16 per workgroup pass.
+        const int slot = lane >> nwp_log, kw = lane & (nwp - 1);
+        const bool wordok = kw < nw;
+        // this lane's word of every role mask / neighbour mask: read from LDS once
+        unsigned long long mA = 0ull, mB = 0ull, mFa = 0ull, mFb = 0ull, oA = 0ull, oB = 0ull, oFa = 0ull, oFb = 0ull;
+        if (wordok) {
+          mA = rmask[kw]; mB = rmask[32 + kw]; mFa = rmask[64 + kw]; mFb = rmask[96 + kw];
+          oA = rolenz[kw]; oB = rolenz[32 + kw]; oFa = rolenz[64 + kw]; oFb = rolenz[96 + kw];
+        }
+        const unsigned long long Tm = mA | mB | mFa | mFb;
+        const unsigned long long segmask = (nwp == 64 ? ~0ull : ((1ull << nwp) - 1ull)) << (slot << nwp_log);
+        for (int xi0 = wv * RP; xi0 < nT; xi0 += 4 * RP) {
+          const int xi = xi0 + slot;
+          int x = -1;
+          if (xi < nT) {
+            if (xi < nA) x = listA[xi];
+            else if (xi < nA + nB) x = listB[xi - nA];
+            else if (xi < nA + nB + nFa) x = listFa[xi - nA - nB];
+            else x = listFb[xi - nA - nB - nFa];
           }
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int x = xs[j];
-            if (x < 0) continue;
-            const int rx = role[x];
-            const unsigned long long bmw = bm[j];
-            for (int k = 0; k < nw; k++) {
-              const unsigned long long word = __shfl(bmw, k, 64);
-              if (word == 0ull) continue;
-              const int b = (k << 6) + lane;
-              const bool bit = (word >> lane) & 1ull;
-              const int rbk = role[b];
-              const bool dies = bit && in_s(rx, rbk, merge);
-              // an edge with both ends in T is listed once, from its lower end
-              const bool lv = bit && !dies && (rbk == ROLE_NONE || x < b);
-              const unsigned long long dm = __ballot(dies), mk = __ballot(lv);
-              if (dm != 0ull && lane == 0) LV[(size_t)x * nw + k] = word & ~dm;
-              if (mk == 0ull) continue;
-              int base = 0;
-              if (lane == 0) base = atomicAdd(&s_items, __popcll(mk));
-              base = __shfl(base, 0, 64);
-              if (lv) {
-                const int idx = base + __popcll(mk & ((1ull << lane) - 1ull));
-                const unsigned int it = ((unsigned)x << 16) | (unsigned)b;
+          unsigned long long lvw = 0ull, nzw = 0ull;
+          if (x >= 0 && wordok) {
+            lvw = LV[(size_t)x * nw + kw];
+            nzw = NZ[(size_t)x * nw + kw];
+          }
+          // the role of x follows from which list it came from
+          const int rx = xi < nA ? ROLE_A : xi < nA + nB ? ROLE_B : xi < nA + nB + nFa ? ROLE_FA : ROLE_FB;
+          const unsigned long long D = rx == ROLE_A ? (mB | mFb) : rx == ROLE_B ? (mA | mFa) : rx == ROLE_FA ? mB : mA;
+          // does a stored row maximum sit on a dying edge?
+          bool hit = false;
+          if (x >= 0) {
+            const unsigned long long kF = bestF[x], kP = bestP[x];
+            const int cF = key_col(kF), cP = key_col(kP);
+            hit = (kF && kw == (cF >> 6) && ((D >> (cF & 63)) & 1ull)) || (kP && kw == (cP >> 6) && ((D >> (cP & 63)) & 1ull));
+          }
+          const unsigned long long hm = __ballot(hit) & segmask;
+          if (hm != 0ull && kw == 0 && x >= 0) {
+            atomicOr(&stalew[x >> 5], 1u << (x & 31));
+            dlist[atomicAdd(&s_nd, 1)] = (unsigned short)x;
+          }
+#ifdef AHK_TIMING
+          AHK_T(6);
+#endif
+          unsigned long long cand = 0ull;
+          if (x >= 0 && wordok) {
+            const unsigned long long lvn = lvw & ~D;
+            const unsigned long long nzn = nzw | D;
+            if (lvn != lvw) LV[(size_t)x * nw + kw] = lvn;
+            if (nzn != nzw) NZ[(size_t)x * nw + kw] = nzn;
+            const int xw = x >> 6;
+            const unsigned long long low = kw < xw ? ~0ull : (kw == xw ? ((1ull << (x & 63)) - 1ull) : 0ull);
+            // columns with a non-zero third edge to some rewritten neighbour of x
+            const unsigned long long nzc = rx == ROLE_A ? (oB | oFb) : rx == ROLE_B ? (oA | oFa) : rx == ROLE_FA ? oB : oA;
+            cand = lvn & (nzc | Tm) & ~(Tm & low);
+          }
+          // Expand the candidate words into list items, one WORD at a time with all
+          // 64 lanes (lane = column bit): neighbours of a read cluster in a few
+          // words (reads are position-sorted), so per-lane serial expansion would
+          // leave most lanes idle.  The word loop is scalar (wave-uniform).
+          unsigned long long todo = __ballot(cand != 0ull);
+          if (todo != 0ull) {
+            const int total = wave_sum_i(__popcll(cand));
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_items, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            while (todo != 0ull) {
+              const int l = __builtin_ctzll(todo);
+              todo &= todo - 1ull;
+              const unsigned long long w = readlane_u64(cand, l);
+              const int xl = __builtin_amdgcn_readlane(x, l);
+              const int rxl = __builtin_amdgcn_readlane(rx, l);
+              const int kwl = l & (nwp - 1);
+              if ((w >> lane) & 1ull) {
+                const int b = (kwl << 6) + lane;
+                const int idx = base + mask_rank(w);
+                const unsigned int it = ((unsigned)rxl << 28) | ((unsigned)role[b] << 24) | ((unsigned)xl << 12) | (unsigned)b;
                 if (idx < cap) items_lds[idx] = it;
                 else items_glb[idx - cap] = it;
               }
-            }
-            if (lane == 0) {  // the row maximum of x is rebuilt from scratch in P3b
-              bestF[x] = 0;
-              bestP[x] = 0;
-              atomicAnd(&stalew[x >> 5], ~(1u << (x & 31)));
+              base += __popcll(w);
             }
           }
+#ifdef AHK_TIMING
+          AHK_T(7);
+#endif
         }
       }
       __syncthreads();
       AHK_T(5);
 
-      // ---- P3b: one lane per listed edge: apply this iteration's changes --------
-      // Each lane takes up to 4 edges per pass and issues all of their first
-      // loads (the edge's induced costs and the first rewritten triangle) before
-      // it consumes any: the pass costs one HBM round trip instead of four.
+      // ---- P3b: one lane per candidate edge ---------------------------------------
       {
         const unsigned int* items_lds = (const unsigned int*)rowbuf;
         const int cap = 2 * nmax;
@@ -571,111 +681,96 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
 #ifdef AHK_TIMING
         sumM += M;
 #endif
-        constexpr int UN = 1;
-        for (int base = tid; base < M; base += kBlock * UN) {
-          int xs[UN], bs[UN], w0s[UN], a0s[UN], c0s[UN];
-          IcPair ics[UN];
+        for (int i = tid; i < M; i += kBlock) {
+          const unsigned int it = i < cap ? items_lds[i] : items_glb[i - cap];
+          const int rx = (int)(it >> 28), rb = (int)((it >> 24) & 7u);
+          const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
+          const size_t ici = ic_index(x, b, n);
+          IcPair ic = IC[ici];  // issued before the triangle loads, used after them
+          long long df = 0, dp = 0;
+          {
+            const unsigned short* L1 = (rx == ROLE_A || rx == ROLE_FA) ? listB : listA;
+            const int n1 = (rx == ROLE_A || rx == ROLE_FA) ? nB : nA;
+            const unsigned short* L2 = rx == ROLE_A ? listFb : listFa;
+            const int n2 = rx == ROLE_A ? nFb : (rx == ROLE_B ? nFa : 0);
+            const int nc = n1 + n2;
+            for (int w0 = 0; w0 < nc; w0 += 4) {
+              // the eight loads of a chunk of four triangles are independent
+              int ws4[4], ov4[4], wb4[4];
 #pragma unroll
-          for (int j = 0; j < UN; j++) {
-            const int i = base + j * kBlock;
-            xs[j] = -1;
-            if (i < M) {
-              const unsigned int it = i < cap ? items_lds[i] : items_glb[i - cap];
-              const int x = (int)(it >> 16), b = (int)(it & 0xffffu);
-              const int rx = role[x];
-              // first rewritten column of row x (its list is never empty)
-              const int w0 = (rx == ROLE_A || rx == ROLE_FA) ? listB[0] : listA[0];
-              xs[j] = x;
-              bs[j] = b;
-              w0s[j] = w0;
-              ics[j] = IC[ic_index(x, b, n)];
-              a0s[j] = Wm[(size_t)x * n + w0];
-              c0s[j] = Wm[(size_t)w0 * n + b];
+              for (int c = 0; c < 4; c++) {
+                const int wi = w0 + c;
+                const int w = wi < n1 ? L1[wi] : (wi < nc ? L2[wi - n1] : -1);
+                ws4[c] = w;
+                ov4[c] = w >= 0 ? Wm[(size_t)x * n + w] : 0;
+                wb4[c] = w >= 0 ? Wm[(size_t)w * n + b] : 0;
+              }
+#pragma unroll
+              for (int c = 0; c < 4; c++) {
+                const int w = ws4[c];
+                if (w < 0) continue;
+                // the role of w follows from the list it sits in
+                const int rw = (w0 + c < n1) ? ((rx == ROLE_A || rx == ROLE_FA) ? ROLE_B : ROLE_A) : (rx == ROLE_A ? ROLE_FB : ROLE_FA);
+                const int Nv = new_w(rx, rw, merge);
+                const int wbo = wb4[c];
+                const int wbn = in_s(rw, rb, merge) ? new_w(rw, rb, merge) : wbo;
+                df += icf_term(Nv, wbn) - icf_term(ov4[c], wbo);
+                dp += icp_term(Nv, wbn) - icp_term(ov4[c], wbo);
+              }
             }
           }
-#pragma unroll
-          for (int j = 0; j < UN; j++) {
-            const int x = xs[j];
-            if (x < 0) continue;
-            const int b = bs[j];
-            const int rx = role[x], rb = role[b];
-            IcPair ic = ics[j];
-            // columns rewritten in row x: two lists, each with its new weight
-            const unsigned short* L1 = nullptr; int n1 = 0, N1 = 0;
-            const unsigned short* L2 = nullptr; int n2 = 0;
-            if (rx == ROLE_A) { L1 = listB; n1 = nB; N1 = merge ? W_PERM : W_FORB; L2 = listFb; n2 = nFb; }
-            else if (rx == ROLE_B) { L1 = listA; n1 = nA; N1 = merge ? W_PERM : W_FORB; L2 = listFa; n2 = nFa; }
-            else if (rx == ROLE_FA) { L1 = listB; n1 = nB; N1 = W_FORB; }
-            else { L1 = listA; n1 = nA; N1 = W_FORB; }
-            long long df = 0, dp = 0;
+          if (rb != ROLE_NONE) {
+            // triangles whose changed edge is (b,w) only: w in C(b) \ C(x)
+            const unsigned short* M1 = (rb == ROLE_A || rb == ROLE_FA) ? listB : listA;
+            const int m1 = (rb == ROLE_A || rb == ROLE_FA) ? nB : nA;
+            const unsigned short* M2 = rb == ROLE_A ? listFb : listFa;
+            const int m2 = rb == ROLE_A ? nFb : (rb == ROLE_B ? nFa : 0);
             for (int pass = 0; pass < 2; pass++) {
-              const unsigned short* L = pass == 0 ? L1 : L2;
-              const int nl = pass == 0 ? n1 : n2;
-              const int Nv = wval(pass == 0 ? N1 : W_FORB);
+              const unsigned short* L = pass == 0 ? M1 : M2;
+              const int nl = pass == 0 ? m1 : m2;
               for (int wi = 0; wi < nl; wi++) {
                 const int w = L[wi];
-                const bool pre = pass == 0 && wi == 0;  // L1[0] == w0: already loaded
-                const int ov = wval(pre ? a0s[j] : Wm[(size_t)x * n + w]);
-                const int wbo = wval(pre ? c0s[j] : Wm[(size_t)w * n + b]);
                 const int rw = role[w];
-                const int wbn = in_s(rw, rb, merge) ? wval(new_w(rw, rb, merge)) : wbo;
-                df += icf_term(Nv, wbn) - icf_term(ov, wbo);
-                dp += icp_term(Nv, wbn) - icp_term(ov, wbo);
+                if (w == x || in_s(rx, rw, merge)) continue;  // (x,w) changes too: counted above
+                const int Nv = new_w(rb, rw, merge);
+                const int ov = Wm[(size_t)w * n + b];
+                const int xw = Wm[(size_t)x * n + w];
+                df += icf_term(Nv, xw) - icf_term(ov, xw);
+                dp += icp_term(Nv, xw) - icp_term(ov, xw);
               }
             }
-            if (rb != ROLE_NONE) {
-              // triangles whose changed edge is (b,w) only: w in C(b) \ C(x)
-              const unsigned short* M1 = nullptr; int m1 = 0, Q1 = 0;
-              const unsigned short* M2 = nullptr; int m2 = 0;
-              if (rb == ROLE_A) { M1 = listB; m1 = nB; Q1 = merge ? W_PERM : W_FORB; M2 = listFb; m2 = nFb; }
-              else if (rb == ROLE_B) { M1 = listA; m1 = nA; Q1 = merge ? W_PERM : W_FORB; M2 = listFa; m2 = nFa; }
-              else if (rb == ROLE_FA) { M1 = listB; m1 = nB; Q1 = W_FORB; }
-              else { M1 = listA; m1 = nA; Q1 = W_FORB; }
-              for (int pass = 0; pass < 2; pass++) {
-                const unsigned short* L = pass == 0 ? M1 : M2;
-                const int nl = pass == 0 ? m1 : m2;
-                const int Nv = wval(pass == 0 ? Q1 : W_FORB);
-                for (int wi = 0; wi < nl; wi++) {
-                  const int w = L[wi];
-                  if (w == x || in_s(rx, role[w], merge)) continue;  // (x,w) changes too: counted above
-                  const int ov = wval(Wm[(size_t)w * n + b]);
-                  const int xw = wval(Wm[(size_t)x * n + w]);
-                  df += icf_term(Nv, xw) - icf_term(ov, xw);
-                  dp += icp_term(Nv, xw) - icp_term(ov, xw);
-                }
-              }
-            }
-            if (df != 0 || dp != 0) {
-              ic.f += df;
-              ic.p += dp;
-              IC[ic_index(x, b, n)] = ic;
+          }
+          if (df == 0 && dp == 0) continue;
+          ic.f += df;
+          ic.p += dp;
+          IC[ici] = ic;
 #ifdef AHK_TIMING
-              atomicAdd(&s_chg, 1);
+          atomicAdd(&s_chg, 1);
 #endif
-            }
-            atomicMax(&bestF[x], mkkey(ic.f, b));
-            atomicMax(&bestP[x], mkkey(ic.p, b));
-            if (rb != ROLE_NONE) {  // both rows are rebuilt from scratch in this pass
-              atomicMax(&bestF[b], mkkey(ic.f, x));
-              atomicMax(&bestP[b], mkkey(ic.p, x));
-            } else {
-              // row b is not revisited as a whole: fold the new value into its row
-              // maximum; if the maximum sat on this very column and went down, the
-              // stored maximum is now only an upper bound -> mark the row stale
-              const unsigned long long c1 = mkkey(ic.f, x), c2 = mkkey(ic.p, x);
-              const unsigned long long k1 = bestF[b], k2 = bestP[b];
-              if ((k1 && key_col(k1) == x && c1 < k1) || (k2 && key_col(k2) == x && c2 < k2))
-                atomicOr(&stalew[b >> 5], 1u << (b & 31));
-              atomicMax(&bestF[b], c1);
-              atomicMax(&bestP[b], c2);
-            }
+          // fold the new value into both row maxima; a maximum that sat on this
+          // edge and went down is now only an upper bound -> mark the row stale
+          {
+            const unsigned long long c1 = mkkey(ic.f, b), c2 = mkkey(ic.p, b);
+            const unsigned long long k1 = bestF[x], k2 = bestP[x];
+            if ((k1 && key_col(k1) == b && c1 < k1) || (k2 && key_col(k2) == b && c2 < k2))
+              atomicOr(&stalew[x >> 5], 1u << (x & 31));
+            atomicMax(&bestF[x], c1);
+            atomicMax(&bestP[x], c2);
+          }
+          {
+            const unsigned long long c1 = mkkey(ic.f, x), c2 = mkkey(ic.p, x);
+            const unsigned long long k1 = bestF[b], k2 = bestP[b];
+            if ((k1 && key_col(k1) == x && c1 < k1) || (k2 && key_col(k2) == x && c2 < k2))
+              atomicOr(&stalew[b >> 5], 1u << (b & 31));
+            atomicMax(&bestF[b], c1);
+            atomicMax(&bestP[b], c2);
           }
         }
       }
       __syncthreads();
       AHK_T(3);
 
-      // ---- P4: rewrite the weights of S, merge the cliques
+      // ---- P4: rewrite the weights of S, merge the cliques, rescan queued rows ----
       {
         const int N1 = merge ? W_PERM : W_FORB;
         for (int xi = 0; xi < nA; xi++) {
@@ -699,15 +794,45 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
           for (int yi = tid; yi < nB; yi += kBlock) cl[listB[yi]] = (unsigned short)cu;
         if (tid < 4) s_cnt[tid] = 0;
         if (tid == 0) s_items = 0;
+        // rows whose maximum died: exact rescan now (they would tie the next argmax anyway)
+        const int nd = s_nd;
+        unsigned short* rb_buf = rowbuf + (size_t)wv * nmax;
+        for (int di = wv; di < nd; di += 4) {
+          const int r = dlist[di];
+          const unsigned long long bmw = lane < nw ? LV[(size_t)r * nw + lane] : 0ull;
+          int Lc = 0;
+          for (int k = 0; k < nw; k++) {
+            const unsigned long long word = __shfl(bmw, k, 64);
+            if (word == 0ull) continue;
+            if ((word >> lane) & 1ull) rb_buf[Lc + __popcll(word & ((1ull << lane) - 1ull))] = (unsigned short)((k << 6) + lane);
+            Lc += __popcll(word);
+          }
+          unsigned long long kF = 0, kP = 0;
+          for (int i = lane; i < Lc; i += 64) {
+            const int b = rb_buf[i];
+            const IcPair v = IC[ic_index(r, b, n)];
+            const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
+            kF = k1 > kF ? k1 : kF;
+            kP = k2 > kP ? k2 : kP;
+          }
+          kF = wave_max_u64(kF);
+          kP = wave_max_u64(kP);
+          if (lane == 0) {
+            bestF[r] = kF;
+            bestP[r] = kP;
+            atomicAnd(&stalew[r >> 5], ~(1u << (r & 31)));
+          }
+        }
       }
       __syncthreads();
+      if (tid == 0) s_nd = 0;  // next append is behind the P1 reduction barrier
       AHK_T(4);
     }
     __syncthreads();
 #ifdef AHK_TIMING
     if (tid == 0 && blockIdx.x == 0)
-      printf("chain %d n=%d iters=%lld retries=%lld rescans=%lld sumT=%lld sumM=%lld sumW=%lld | cycles P1=%lld resc=%lld P2=%lld P3a=%lld P3b=%lld P4=%lld\n", c, n, iters,
-             nretry, nresc, sumT, sumM, (long long)s_chg, tacc[0], tacc[1], tacc[2], tacc[5], tacc[3], tacc[4]);
+      printf("chain %d n=%d iters=%lld retries=%lld rescans=%lld sumT=%lld sumM=%lld sumW=%lld | cycles P1=%lld resc=%lld P2=%lld P3a=%lld (loadwait=%lld proc=%lld) P3b=%lld P4=%lld | t8=%lld t9=%lld\n", c, n, iters,
+             nretry, nresc, sumT, sumM, (long long)s_chg, tacc[0], tacc[1], tacc[2], tacc[5], tacc[6], tacc[7], tacc[3], tacc[4], tacc[8], tacc[9]);
 #endif
     if (lds.stop_after == 3) continue;
 
@@ -956,7 +1081,8 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   size_t b = (size_t)l.nmax * 8 * 2;       // bestF, bestP
   b += (size_t)l.nmax * 2 * 5;             // cl + 4 lists
   b += (size_t)l.nmax * 2 * 5;             // rowbuf[4], dlist
-  b += (size_t)((l.nmax + 31) / 32) * 4;   // stalew
+  b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4;  // stalew (padded to 8 bytes)
+  b += 2 * 4 * 32 * 8;                                   // rmask, rolenz
   b += (size_t)l.nmax;                     // role
   return (b + 15) & ~(size_t)15;
 }

@@ -54,6 +54,8 @@ struct ahsoka_device_batch {
   PhaseLds pl;
   int* queue = nullptr;
   int* qhead = nullptr;
+  DeviceBatch* db_dev = nullptr;     // copies of db / ws in device memory (k_phase reads them by pointer)
+  SlotWorkspace* ws_dev = nullptr;
   int slots = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -333,6 +335,7 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   if ((rc = h->dalloc(&ws.W, S * ws.nmax * ws.nmax))) return fail(rc);
   if ((rc = h->dalloc(&ws.IC, S * ws.nmax * ws.nmax))) return fail(rc);
   if ((rc = h->dalloc(&ws.live, S * ws.nmax * ((ws.nmax + 63) / 64)))) return fail(rc);
+  if ((rc = h->dalloc(&ws.nz, S * ws.nmax * ((ws.nmax + 63) / 64)))) return fail(rc);
   if ((rc = h->dalloc(&ws.items, S * ws.nmax * ws.nmax))) return fail(rc);
   if ((rc = h->dalloc(&ws.rates, S * 2 * ws.nmax))) return fail(rc);
   if ((rc = h->dalloc(&ws.tp_k, S * ws.Pmax))) return fail(rc);
@@ -360,6 +363,14 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
     h->queue = const_cast<int*>(q);
   }
   if ((rc = h->dalloc(&h->qhead, 1))) return fail(rc);
+  {
+    const DeviceBatch* d = nullptr;
+    const SlotWorkspace* w = nullptr;
+    if ((rc = h->dupload(&d, &h->db, 1))) return fail(rc);
+    if ((rc = h->dupload(&w, &h->ws, 1))) return fail(rc);
+    h->db_dev = const_cast<DeviceBatch*>(d);
+    h->ws_dev = const_cast<SlotWorkspace*>(w);
+  }
   if (hipStreamCreate(&h->stream) != hipSuccess) return fail(AHSOKA_E_HIP);
   for (int i = 0; i < 3; i++)
     if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(AHSOKA_E_HIP);

@@ -79,6 +79,7 @@ struct SlotWorkspace {
   int* W;               // [slots][nmax*nmax]
   IcPair* IC;           // [slots][nmax*nmax]
   unsigned long long* live;  // [slots][nmax*ceil(nmax/64)] live-edge bitmap rows
+  unsigned long long* nz;    // same shape: W[x][b] != 0 (finite or resolved)
   unsigned int* items;       // [slots][nmax*nmax] overflow of the per-iteration edge list
   double* rates;        // [slots][2*nmax]   same_i, diff_i
   // threading tables
