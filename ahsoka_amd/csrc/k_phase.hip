@@ -161,7 +161,10 @@ __device__ __forceinline__ void pair_overlap(const ChainCtx& cx, int i, int j, i
 // global_load/global_store.  Read through a pointer-to-struct they degrade to
 // flat_* instructions, which count on lgkmcnt as well -- every LDS wait then
 // also waits for all outstanding HBM traffic (measured: whole-kernel slowdown).
-__global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
+#ifndef AHK_WAVES_PER_SIMD
+#define AHK_WAVES_PER_SIMD 5
+#endif
+__global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
                                                      int C, int* __restrict__ qhead) {
   extern __shared__ __align__(16) unsigned long long smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -183,8 +186,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
 #ifdef AHK_TIMING
   __shared__ int s_chg;
 #endif
-  __shared__ long long s_rv[16];
-  __shared__ unsigned int s_rab[8];
+  __shared__ unsigned long long s_rk[16];
   __shared__ int s_asc[4][8];
   __shared__ int s_back;
 
@@ -406,54 +408,49 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
       long long vf, vp;
       unsigned int abf, abp;
       for (;;) {
-        vf = -1; vp = -1;
-        abf = 0xFFFFFFFFu; abp = 0xFFFFFFFFu;
-        long long sF = -1, sP = -1;
+        // global key of an edge: (value+1) << 22 | (2047-u) << 11 | (2047-v), u < v:
+        // one 64-bit max gives the largest value and, among equals, the
+        // lexicographically smallest pair.  value+1 < 2^42 (weights are clamped to
+        // 2^30, n <= 2048).  0 = no live edge.
+        unsigned long long gF = 0ull, gP = 0ull, tF = 0ull, tP = 0ull;
         for (int u = tid; u < n; u += kBlock) {
           const unsigned long long k1 = bestF[u], k2 = bestP[u];
           const bool st = (stalew[u >> 5] >> (u & 31)) & 1u;
           if (k1) {
             const int cc = key_col(k1);
-            const long long v = key_val(k1);
-            const unsigned int ab = u < cc ? ((unsigned)u << 16 | (unsigned)cc) : ((unsigned)cc << 16 | (unsigned)u);
-            if (v > vf || (v == vf && ab < abf)) { vf = v; abf = ab; }
-            if (st && v > sF) sF = v;
+            const unsigned int a = u < cc ? u : cc, b = u < cc ? cc : u;
+            const unsigned long long g = ((k1 >> 12) << 22) | ((unsigned long long)(2047u - a) << 11) | (unsigned long long)(2047u - b);
+            gF = g > gF ? g : gF;
+            if (st && (k1 >> 12) > tF) tF = k1 >> 12;
           }
           if (k2) {
             const int cc = key_col(k2);
-            const long long v = key_val(k2);
-            const unsigned int ab = u < cc ? ((unsigned)u << 16 | (unsigned)cc) : ((unsigned)cc << 16 | (unsigned)u);
-            if (v > vp || (v == vp && ab < abp)) { vp = v; abp = ab; }
-            if (st && v > sP) sP = v;
+            const unsigned int a = u < cc ? u : cc, b = u < cc ? cc : u;
+            const unsigned long long g = ((k2 >> 12) << 22) | ((unsigned long long)(2047u - a) << 11) | (unsigned long long)(2047u - b);
+            gP = g > gP ? g : gP;
+            if (st && (k2 >> 12) > tP) tP = k2 >> 12;
           }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const long long tv = __shfl_xor(vf, o, 64);
-          const unsigned int ta = __shfl_xor(abf, o, 64);
-          if (tv > vf || (tv == vf && ta < abf)) { vf = tv; abf = ta; }
-          const long long tv2 = __shfl_xor(vp, o, 64);
-          const unsigned int ta2 = __shfl_xor(abp, o, 64);
-          if (tv2 > vp || (tv2 == vp && ta2 < abp)) { vp = tv2; abp = ta2; }
-          const long long t3 = __shfl_xor(sF, o, 64), t4 = __shfl_xor(sP, o, 64);
-          sF = t3 > sF ? t3 : sF;
-          sP = t4 > sP ? t4 : sP;
-        }
+        gF = wave_max_u64(gF);
+        gP = wave_max_u64(gP);
+        tF = wave_max_u64(tF);
+        tP = wave_max_u64(tP);
         if (lane == 0) {
-          s_rv[wv] = vf; s_rab[wv] = abf;
-          s_rv[4 + wv] = vp; s_rab[4 + wv] = abp;
-          s_rv[8 + wv] = sF; s_rv[12 + wv] = sP;
+          s_rk[wv] = gF; s_rk[4 + wv] = gP; s_rk[8 + wv] = tF; s_rk[12 + wv] = tP;
         }
         __syncthreads();
-        vf = s_rv[0]; abf = s_rab[0]; vp = s_rv[4]; abp = s_rab[4];
-        sF = s_rv[8]; sP = s_rv[12];
 #pragma unroll
-        for (int k = 1; k < 4; k++) {
-          if (s_rv[k] > vf || (s_rv[k] == vf && s_rab[k] < abf)) { vf = s_rv[k]; abf = s_rab[k]; }
-          if (s_rv[4 + k] > vp || (s_rv[4 + k] == vp && s_rab[4 + k] < abp)) { vp = s_rv[4 + k]; abp = s_rab[4 + k]; }
-          sF = s_rv[8 + k] > sF ? s_rv[8 + k] : sF;
-          sP = s_rv[12 + k] > sP ? s_rv[12 + k] : sP;
+        for (int k = 0; k < 4; k++) {
+          gF = s_rk[k] > gF ? s_rk[k] : gF;
+          gP = s_rk[4 + k] > gP ? s_rk[4 + k] : gP;
+          tF = s_rk[8 + k] > tF ? s_rk[8 + k] : tF;
+          tP = s_rk[12 + k] > tP ? s_rk[12 + k] : tP;
         }
+        vf = (long long)(gF >> 22) - 1;
+        vp = (long long)(gP >> 22) - 1;
+        abf = ((2047u - (unsigned)((gF >> 11) & 2047u)) << 16) | (2047u - (unsigned)(gF & 2047u));
+        abp = ((2047u - (unsigned)((gP >> 11) & 2047u)) << 16) | (2047u - (unsigned)(gP & 2047u));
+        const long long sF = (long long)tF - 1, sP = (long long)tP - 1;
         const bool need = (sF >= 0 && sF == vf) || (sP >= 0 && sP == vp);
         AHK_T(0);
         if (!need) break;  // uniform
@@ -466,25 +463,24 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
         __syncthreads();
         {
           const int nd = s_nd;
-          unsigned short* rb_buf = rowbuf + (size_t)wv * nmax;
           for (int di = wv; di < nd; di += 4) {
             const int r = dlist[di];
+            // live columns word by word (scalar loop over the non-empty words); the
+            // loads of all words are in flight together, consumed by the max below
             const unsigned long long bmw = lane < nw ? LV[(size_t)r * nw + lane] : 0ull;
-            int Lc = 0;
-            for (int k = 0; k < nw; k++) {
-              const unsigned long long word = __shfl(bmw, k, 64);
-              if (word == 0ull) continue;
-              const bool lv = (word >> lane) & 1ull;
-              if (lv) rb_buf[Lc + __popcll(word & ((1ull << lane) - 1ull))] = (unsigned short)((k << 6) + lane);
-              Lc += __popcll(word);
-            }
+            unsigned long long todo = __ballot(bmw != 0ull);
             unsigned long long kF = 0, kP = 0;
-            for (int i = lane; i < Lc; i += 64) {
-              const int b = rb_buf[i];
-              const IcPair v = IC[ic_index(r, b, n)];
-              const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
-              kF = k1 > kF ? k1 : kF;
-              kP = k2 > kP ? k2 : kP;
+            while (todo != 0ull) {
+              const int l = __builtin_ctzll(todo);
+              todo &= todo - 1ull;
+              const unsigned long long w = readlane_u64(bmw, l);
+              if ((w >> lane) & 1ull) {
+                const int b = (l << 6) + lane;
+                const IcPair v = IC[ic_index(r, b, n)];
+                const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
+                kF = k1 > kF ? k1 : kF;
+                kP = k2 > kP ? k2 : kP;
+              }
             }
             kF = wave_max_u64(kF);
             kP = wave_max_u64(kP);
@@ -688,17 +684,20 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
           const size_t ici = ic_index(x, b, n);
           IcPair ic = IC[ici];  // issued before the triangle loads, used after them
           long long df = 0, dp = 0;
+#ifdef AHK_TIMING
+          AHK_T(8);
+#endif
           {
             const unsigned short* L1 = (rx == ROLE_A || rx == ROLE_FA) ? listB : listA;
             const int n1 = (rx == ROLE_A || rx == ROLE_FA) ? nB : nA;
             const unsigned short* L2 = rx == ROLE_A ? listFb : listFa;
             const int n2 = rx == ROLE_A ? nFb : (rx == ROLE_B ? nFa : 0);
             const int nc = n1 + n2;
-            for (int w0 = 0; w0 < nc; w0 += 4) {
-              // the eight loads of a chunk of four triangles are independent
-              int ws4[4], ov4[4], wb4[4];
+            for (int w0 = 0; w0 < nc; w0 += 8) {
+              // the sixteen loads of a chunk of eight triangles are independent
+              int ws4[8], ov4[8], wb4[8];
 #pragma unroll
-              for (int c = 0; c < 4; c++) {
+              for (int c = 0; c < 8; c++) {
                 const int wi = w0 + c;
                 const int w = wi < n1 ? L1[wi] : (wi < nc ? L2[wi - n1] : -1);
                 ws4[c] = w;
@@ -706,7 +705,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
                 wb4[c] = w >= 0 ? Wm[(size_t)w * n + b] : 0;
               }
 #pragma unroll
-              for (int c = 0; c < 4; c++) {
+              for (int c = 0; c < 8; c++) {
                 const int w = ws4[c];
                 if (w < 0) continue;
                 // the role of w follows from the list it sits in
@@ -740,6 +739,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
               }
             }
           }
+#ifdef AHK_TIMING
+          AHK_T(9);
+#endif
           if (df == 0 && dp == 0) continue;
           ic.f += df;
           ic.p += dp;
@@ -765,29 +767,41 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
             atomicMax(&bestF[b], c1);
             atomicMax(&bestP[b], c2);
           }
+#ifdef AHK_TIMING
+          AHK_T(10);
+#endif
         }
       }
+#ifdef AHK_TIMING
+      AHK_T(10);
+#endif
       __syncthreads();
       AHK_T(3);
 
       // ---- P4: rewrite the weights of S, merge the cliques, rescan queued rows ----
       {
         const int N1 = merge ? W_PERM : W_FORB;
-        for (int xi = 0; xi < nA; xi++) {
-          const int x = listA[xi];
-          for (int yi = tid; yi < nB + nFb; yi += kBlock) {
-            const int y = yi < nB ? listB[yi] : listFb[yi - nB];
-            const int N = yi < nB ? N1 : W_FORB;
+        // all rewritten pairs, flattened over the workgroup: A x (B u Fb), then B x Fa
+        // (a big clique against a single read is 300 pairs, not 300 loop trips)
+        {
+          const int ny = nB + nFb;
+          const int np1 = nA * ny, np2 = nB * nFa;
+          for (int i = tid; i < np1 + np2; i += kBlock) {
+            int x, y, N;
+            if (i < np1) {
+              const int xi = i / ny, yi = i - xi * ny;
+              x = listA[xi];
+              y = yi < nB ? listB[yi] : listFb[yi - nB];
+              N = yi < nB ? N1 : W_FORB;
+            } else {
+              const int j = i - np1;
+              const int xi = j / nFa, yi = j - xi * nFa;
+              x = listB[xi];
+              y = listFa[yi];
+              N = W_FORB;
+            }
             Wm[(size_t)x * n + y] = N;
             Wm[(size_t)y * n + x] = N;
-          }
-        }
-        for (int xi = 0; xi < nB; xi++) {
-          const int x = listB[xi];
-          for (int yi = tid; yi < nFa; yi += kBlock) {
-            const int y = listFa[yi];
-            Wm[(size_t)x * n + y] = W_FORB;
-            Wm[(size_t)y * n + x] = W_FORB;
           }
         }
         if (merge)
@@ -796,24 +810,22 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
         if (tid == 0) s_items = 0;
         // rows whose maximum died: exact rescan now (they would tie the next argmax anyway)
         const int nd = s_nd;
-        unsigned short* rb_buf = rowbuf + (size_t)wv * nmax;
         for (int di = wv; di < nd; di += 4) {
           const int r = dlist[di];
           const unsigned long long bmw = lane < nw ? LV[(size_t)r * nw + lane] : 0ull;
-          int Lc = 0;
-          for (int k = 0; k < nw; k++) {
-            const unsigned long long word = __shfl(bmw, k, 64);
-            if (word == 0ull) continue;
-            if ((word >> lane) & 1ull) rb_buf[Lc + __popcll(word & ((1ull << lane) - 1ull))] = (unsigned short)((k << 6) + lane);
-            Lc += __popcll(word);
-          }
+          unsigned long long todo = __ballot(bmw != 0ull);
           unsigned long long kF = 0, kP = 0;
-          for (int i = lane; i < Lc; i += 64) {
-            const int b = rb_buf[i];
-            const IcPair v = IC[ic_index(r, b, n)];
-            const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
-            kF = k1 > kF ? k1 : kF;
-            kP = k2 > kP ? k2 : kP;
+          while (todo != 0ull) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const unsigned long long w = readlane_u64(bmw, l);
+            if ((w >> lane) & 1ull) {
+              const int b = (l << 6) + lane;
+              const IcPair v = IC[ic_index(r, b, n)];
+              const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
+              kF = k1 > kF ? k1 : kF;
+              kP = k2 > kP ? k2 : kP;
+            }
           }
           kF = wave_max_u64(kF);
           kP = wave_max_u64(kP);
@@ -831,8 +843,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_phase(DeviceBatch db, SlotWorkspa
     __syncthreads();
 #ifdef AHK_TIMING
     if (tid == 0 && blockIdx.x == 0)
-      printf("chain %d n=%d iters=%lld retries=%lld rescans=%lld sumT=%lld sumM=%lld sumW=%lld | cycles P1=%lld resc=%lld P2=%lld P3a=%lld (loadwait=%lld proc=%lld) P3b=%lld P4=%lld | t8=%lld t9=%lld\n", c, n, iters,
-             nretry, nresc, sumT, sumM, (long long)s_chg, tacc[0], tacc[1], tacc[2], tacc[5], tacc[6], tacc[7], tacc[3], tacc[4], tacc[8], tacc[9]);
+      printf("chain %d n=%d iters=%lld retries=%lld rescans=%lld sumT=%lld sumM=%lld sumW=%lld | cycles P1=%lld resc=%lld P2=%lld P3a=%lld (loadwait=%lld proc=%lld) P3b=%lld P4=%lld | P3b: decode=%lld tri=%lld fold=%lld\n", c, n, iters,
+             nretry, nresc, sumT, sumM, (long long)s_chg, tacc[0], tacc[1], tacc[2], tacc[5], tacc[6], tacc[7], tacc[3], tacc[4], tacc[8], tacc[9], tacc[10]);
 #endif
     if (lds.stop_after == 3) continue;
 

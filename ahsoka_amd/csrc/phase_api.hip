@@ -54,8 +54,9 @@ struct ahsoka_device_batch {
   PhaseLds pl;
   int* queue = nullptr;
   int* qhead = nullptr;
-  DeviceBatch* db_dev = nullptr;     // copies of db / ws in device memory (k_phase reads them by pointer)
-  SlotWorkspace* ws_dev = nullptr;
+  int maxG = 1, maxB = 1, n_cu = 1;
+  size_t lds_per_block = 0;
+  bool ws_ready = false;
   int slots = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -303,51 +304,16 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   h->rl.wordsN = (maxN + 63) / 64;
   h->rl.maxG = maxG;
   h->rl.maxB = maxB;
-  h->pl.nmax = std::min(maxG, kMaxReads);
-  // 16-byte friendly capacity
-  h->pl.nmax = (h->pl.nmax + 7) & ~7;
+  h->maxG = maxG;
+  h->maxB = maxB;
+  h->pl.nmax = 0;  // the slot workspace is sized after the first k_readset (see alloc_slots)
   h->pl.stop_after = 0;
   if (const char* sa = std::getenv("AHSOKA_STOP_AFTER")) h->pl.stop_after = std::atoi(sa);  // profiling aid
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, prm->device) != hipSuccess) return fail(AHSOKA_E_NODEVICE);
-  if (readset_lds_bytes(h->rl) > (size_t)prop.sharedMemPerBlock || phase_lds_bytes(h->pl) > (size_t)prop.sharedMemPerBlock)
-    return fail(AHSOKA_E_UNSUPPORTED);
-  const int per_cu = std::min(phase_max_blocks_per_cu(h->pl), 4);
-  int slots = std::min(C, prop.multiProcessorCount * per_cu);
-  if (slots < 1) slots = 1;
-  // slot workspace: W (4 B) + IC (16 B) per pair dominates; keep it under 60 % of free HBM
-  SlotWorkspace& ws = h->ws;
-  ws.nmax = h->pl.nmax;
-  ws.Pmax = maxB;
-  long long T = 1;
-  for (int i = 0; i < prm->ploidy; i++) T *= 2 * prm->ploidy;
-  ws.Tmax = T;
-  {
-    size_t freeb = 0, totalb = 0;
-    if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) return fail(AHSOKA_E_HIP);
-    const double per_slot = (double)ws.nmax * ws.nmax * 24.2 + (double)ws.Pmax * ws.Tmax * 14.0 + 1e5;
-    const long long fit = (long long)((double)freeb * 0.6 / per_slot);
-    if (fit < 1) return fail(AHSOKA_E_NOMEM);
-    if (slots > fit) slots = (int)fit;
-  }
-  h->slots = slots;
-  const size_t S = (size_t)slots;
-  if ((rc = h->dalloc(&ws.W, S * ws.nmax * ws.nmax))) return fail(rc);
-  if ((rc = h->dalloc(&ws.IC, S * ws.nmax * ws.nmax))) return fail(rc);
-  if ((rc = h->dalloc(&ws.live, S * ws.nmax * ((ws.nmax + 63) / 64)))) return fail(rc);
-  if ((rc = h->dalloc(&ws.nz, S * ws.nmax * ((ws.nmax + 63) / 64)))) return fail(rc);
-  if ((rc = h->dalloc(&ws.items, S * ws.nmax * ws.nmax))) return fail(rc);
-  if ((rc = h->dalloc(&ws.rates, S * 2 * ws.nmax))) return fail(rc);
-  if ((rc = h->dalloc(&ws.tp_k, S * ws.Pmax))) return fail(rc);
-  if ((rc = h->dalloc(&ws.tp_gcid, S * ws.Pmax * 8))) return fail(rc);
-  if ((rc = h->dalloc(&ws.tp_cov, S * ws.Pmax * 8))) return fail(rc);
-  if ((rc = h->dalloc(&ws.tp_cons, S * ws.Pmax * 8))) return fail(rc);
-  if ((rc = h->dalloc(&ws.tp_consmap, S * ws.Pmax * 8))) return fail(rc);
-  if ((rc = h->dalloc(&ws.tp_ntup, S * ws.Pmax))) return fail(rc);
-  if ((rc = h->dalloc(&ws.tp_tuples, S * ws.Pmax * ws.Tmax))) return fail(rc);
-  if ((rc = h->dalloc(&ws.tp_score, S * ws.Pmax * ws.Tmax))) return fail(rc);
-  if ((rc = h->dalloc(&ws.tp_pred, S * ws.Pmax * ws.Tmax))) return fail(rc);
-  if ((rc = h->dalloc(&ws.sortbuf, S * 4 * ws.nmax))) return fail(rc);
+  h->n_cu = prop.multiProcessorCount;
+  h->lds_per_block = (size_t)prop.sharedMemPerBlock;
+  if (readset_lds_bytes(h->rl) > h->lds_per_block) return fail(AHSOKA_E_UNSUPPORTED);
 
   // work queue: largest chains first (the reference orders chains by size too,
   // src/polyassembly.cpp:136-140; here it balances the persistent grid)
@@ -363,18 +329,64 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
     h->queue = const_cast<int*>(q);
   }
   if ((rc = h->dalloc(&h->qhead, 1))) return fail(rc);
-  {
-    const DeviceBatch* d = nullptr;
-    const SlotWorkspace* w = nullptr;
-    if ((rc = h->dupload(&d, &h->db, 1))) return fail(rc);
-    if ((rc = h->dupload(&w, &h->ws, 1))) return fail(rc);
-    h->db_dev = const_cast<DeviceBatch*>(d);
-    h->ws_dev = const_cast<SlotWorkspace*>(w);
-  }
   if (hipStreamCreate(&h->stream) != hipSuccess) return fail(AHSOKA_E_HIP);
   for (int i = 0; i < 3; i++)
     if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(AHSOKA_E_HIP);
   *handle = h;
+  return AHSOKA_OK;
+}
+
+// The per-slot state of k_phase (W, IC, bitmaps: ~24 B per read pair) is sized
+// by the largest FINAL readset, which is only known after k_readset has run
+// (reads are filtered by identity and variant count: ~600 of 1000 survive at
+// config 3).  Sizing by it instead of by the number of read names shrinks the
+// footprint of the 1024 chains in flight 2-3x (fewer TLB misses, better L2 reuse).
+static int alloc_slots(ahsoka_device_batch* h) {
+  std::vector<int> nfin((size_t)h->C);
+  if (hipMemcpy(nfin.data(), h->db.nfin, (size_t)h->C * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return AHSOKA_E_HIP;
+  int nact = 8;
+  for (int v : nfin) nact = std::max(nact, v);
+  h->pl.nmax = (std::min(nact, kMaxReads) + 63) & ~63;
+  if (phase_lds_bytes(h->pl) > h->lds_per_block) return AHSOKA_E_UNSUPPORTED;
+  int per_cu_cap = 5;
+  if (const char* e = std::getenv("AHSOKA_WG_PER_CU")) per_cu_cap = std::max(1, std::atoi(e));  // tuning aid
+  const int per_cu = std::min(phase_max_blocks_per_cu(h->pl), per_cu_cap);
+  int slots = std::min(h->C, h->n_cu * per_cu);
+  if (slots < 1) slots = 1;
+  SlotWorkspace& ws = h->ws;
+  ws.nmax = h->pl.nmax;
+  ws.Pmax = h->maxB;
+  long long T = 1;
+  for (int i = 0; i < h->prm.ploidy; i++) T *= 2 * h->prm.ploidy;
+  ws.Tmax = T;
+  {
+    size_t freeb = 0, totalb = 0;
+    if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) return AHSOKA_E_HIP;
+    const double per_slot = (double)ws.nmax * ws.nmax * 24.2 + (double)ws.Pmax * ws.Tmax * 14.0 + 1e5;
+    const long long fit = (long long)((double)freeb * 0.6 / per_slot);
+    if (fit < 1) return AHSOKA_E_NOMEM;
+    if (slots > fit) slots = (int)fit;
+  }
+  h->slots = slots;
+  const size_t S = (size_t)slots;
+  int rc;
+  if ((rc = h->dalloc(&ws.W, S * ws.nmax * ws.nmax))) return rc;
+  if ((rc = h->dalloc(&ws.IC, S * ws.nmax * ws.nmax))) return rc;
+  if ((rc = h->dalloc(&ws.live, S * ws.nmax * ((ws.nmax + 63) / 64)))) return rc;
+  if ((rc = h->dalloc(&ws.nz, S * ws.nmax * ((ws.nmax + 63) / 64)))) return rc;
+  if ((rc = h->dalloc(&ws.items, S * ws.nmax * ws.nmax))) return rc;
+  if ((rc = h->dalloc(&ws.rates, S * 2 * ws.nmax))) return rc;
+  if ((rc = h->dalloc(&ws.tp_k, S * ws.Pmax))) return rc;
+  if ((rc = h->dalloc(&ws.tp_gcid, S * ws.Pmax * 8))) return rc;
+  if ((rc = h->dalloc(&ws.tp_cov, S * ws.Pmax * 8))) return rc;
+  if ((rc = h->dalloc(&ws.tp_cons, S * ws.Pmax * 8))) return rc;
+  if ((rc = h->dalloc(&ws.tp_consmap, S * ws.Pmax * 8))) return rc;
+  if ((rc = h->dalloc(&ws.tp_ntup, S * ws.Pmax))) return rc;
+  if ((rc = h->dalloc(&ws.tp_tuples, S * ws.Pmax * ws.Tmax))) return rc;
+  if ((rc = h->dalloc(&ws.tp_score, S * ws.Pmax * ws.Tmax))) return rc;
+  if ((rc = h->dalloc(&ws.tp_pred, S * ws.Pmax * ws.Tmax))) return rc;
+  if ((rc = h->dalloc(&ws.sortbuf, S * 4 * ws.nmax))) return rc;
+  h->ws_ready = true;
   return AHSOKA_OK;
 }
 
@@ -387,6 +399,10 @@ extern "C" int ahsoka_phase_device(ahsoka_device_batch* h) {
   HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   launch_readset(h->db, h->C, h->rl, h->stream);
   HIP_TRY(hipGetLastError());
+  if (!h->ws_ready) {  // first call only: size the slot workspace by the real readsets
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = alloc_slots(h)) return rc;
+  }
   HIP_TRY(hipEventRecord(h->ev[1], h->stream));
   launch_phase(h->db, h->ws, h->pl, h->queue, h->C, h->qhead, h->slots, h->stream);
   HIP_TRY(hipGetLastError());

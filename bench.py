@@ -154,7 +154,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.config, per_gpu),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": kp,
                 "k_readset_ms": float(np.mean(k_readset_ms)),
@@ -172,6 +172,23 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(config, chains):
+    """HBM bytes of one k_phase launch from the committed rocprofv3 PMC summary
+    (FETCH_SIZE + WRITE_SIZE, tools/pmc.sh) of this very workload; None if the
+    summary is for another workload.  Raw counter sum: FETCH_SIZE is uncalibrated
+    for k_phase's scattered reads (profiles/*pmc_hbm.json gives both readings)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("config") == config and d.get("chains") == chains:
+            return d["kernels"]["k_phase"]["hbm_bytes_raw"]
+    return None
 
 
 def cpu_baseline(cfg, prm, n_sample):
