@@ -53,54 +53,69 @@ def chain_cost(n_reads: np.ndarray, n_bubbles: np.ndarray) -> np.ndarray:
 
 
 def pack_records(res: PhaseResult, max_chains: int, max_pos: int) -> np.ndarray:
-    """Fixed-size int32 record per chain: [status, P, pos[max_pos], hap[ploidy*max_pos]]."""
+    """Fixed-size int32 record per chain: [status, P, pos[max_pos], hap[ploidy*max_pos]]
+    (vectorised: 10^4 chains per step must not cost Python-loop time)."""
     p = res.ploidy
+    C = res.n_chains
     width = 2 + max_pos + p * max_pos
     rec = np.full((max_chains, width), -1, dtype=np.int32)
-    for c in range(res.n_chains):
-        pos = res.chain_pos(c)
-        P = len(pos)
-        rec[c, 0] = res.status[c]
-        rec[c, 1] = P
-        rec[c, 2:2 + P] = pos
-        haps = res.chain_haps(c)
+    if C == 0:
+        return rec
+    P = np.diff(res.pos_off).astype(np.int64)
+    rec[:C, 0] = res.status
+    rec[:C, 1] = P
+    total = int(res.pos_off[-1])
+    if total:
+        row = np.repeat(np.arange(C), P)
+        col = np.arange(total) - np.repeat(res.pos_off[:-1], P)
+        rec[row, 2 + col] = res.pos
+        base = p * np.repeat(res.pos_off[:-1], P)
+        Prep = np.repeat(P, P)
         for i in range(p):
-            rec[c, 2 + max_pos + i * max_pos: 2 + max_pos + i * max_pos + P] = haps[i]
+            rec[row, 2 + max_pos + i * max_pos + col] = res.hap_allele[base + i * Prep + col]
     return rec
 
 
 def unpack_records(rec: np.ndarray, ploidy: int, max_pos: int):
     """-> (status, pos_off, pos, hap_allele) in the order of the rows of rec
     (rows with status -1 are padding and are dropped)."""
-    keep = rec[:, 0] >= 0
-    rec = rec[keep]
-    status = rec[:, 0].copy()
+    rec = rec[rec[:, 0] >= 0]
+    C = len(rec)
+    status = rec[:, 0].astype(np.int32)
     P = rec[:, 1].astype(np.int64)
     pos_off = np.concatenate([[0], np.cumsum(P)]).astype(np.int64)
-    pos = np.concatenate([rec[c, 2:2 + P[c]] for c in range(len(rec))] or [np.zeros(0, np.int32)]).astype(np.int32)
-    hap = []
-    for c in range(len(rec)):
-        for i in range(ploidy):
-            o = 2 + max_pos + i * max_pos
-            hap.append(rec[c, o:o + P[c]])
-    hap_allele = np.concatenate(hap or [np.zeros(0, np.int32)]).astype(np.int32)
-    return status, pos_off, pos, hap_allele
+    total = int(pos_off[-1])
+    if total == 0:
+        return status, pos_off, np.zeros(0, np.int32), np.zeros(0, np.int32)
+    row = np.repeat(np.arange(C), P)
+    col = np.arange(total) - np.repeat(pos_off[:-1], P)
+    pos = rec[row, 2 + col].astype(np.int32)
+    hap = np.empty(ploidy * total, dtype=np.int32)
+    base = ploidy * np.repeat(pos_off[:-1], P)
+    Prep = np.repeat(P, P)
+    for i in range(ploidy):
+        hap[base + i * Prep + col] = rec[row, 2 + max_pos + i * max_pos + col]
+    return status, pos_off, pos, hap
 
 
-def gather_to_rank0(res: PhaseResult, owned: np.ndarray, n_total: int, max_pos: int, device=None, group=None):
+def gather_to_rank0(res: PhaseResult, owned: np.ndarray, n_total: int, max_pos: int, device=None, group=None,
+                    max_chains: Optional[int] = None):
     """The single collective of the path.  ``owned`` = global chain indices of this
     rank's shard, in the order the shard was phased.  Returns on rank 0
     (status, pos_off, pos, hap_allele) for all n_total chains in global chain
-    order, on other ranks None."""
+    order, on other ranks None.  ``max_chains`` = largest shard (records are
+    padded to it); a block partition knows it without communication, otherwise
+    it is agreed on with one extra tiny all_gather."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = device if device is not None else torch.device("cpu")
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([len(owned)], dtype=torch.int64, device=dev), group=group)
-    max_chains = int(max(int(c.item()) for c in counts))
+    if max_chains is None:
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([len(owned)], dtype=torch.int64, device=dev), group=group)
+        max_chains = int(max(int(c.item()) for c in counts))
     rec = pack_records(res, max_chains, max_pos)
     idx = np.full(max_chains, -1, dtype=np.int32)
     idx[: len(owned)] = owned

@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", help="BASELINE config (c3 = headline); others for experiments")
     ap.add_argument("--chains", type=int, default=0, help="override chains per GPU (experiments only)")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="chains timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="chains timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -54,11 +54,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the phasing path has no CPU fallback")
+    # rehearsal aid (one-GPU box): AHSOKA_BENCH_BACKEND=gloo runs every rank on cuda:0 and
+    # gathers over gloo; the driver's multi-GPU runs use the default, nccl = RCCL over xGMI
+    backend = os.environ.get("AHSOKA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     cfg = dict(capi.CONFIGS[args.config])
     per_gpu = args.chains if args.chains > 0 else cfg["n_chains"]
@@ -84,7 +93,7 @@ def main():
         res = dev.download()
         gathered = None
         if world > 1:
-            gathered = shard.gather_to_rank0(res, owned, per_gpu * world, max_pos, device=device)
+            gathered = shard.gather_to_rank0(res, owned, per_gpu * world, max_pos, device=coll_device, max_chains=per_gpu)
         return res, gathered
 
     def fence():
@@ -106,13 +115,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     phased = res.phased_bubbles(bubble_off)
     if world > 1:
-        t = torch.tensor([phased], dtype=torch.int64, device=device)
+        t = torch.tensor([phased], dtype=torch.int64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_phased = int(t.item())
     else:
