@@ -130,6 +130,31 @@ __device__ __forceinline__ size_t ic_index(int a, int b, int n) {
   return a < b ? (size_t)a * n + b : (size_t)b * n + a;
 }
 
+// Exact maximum of row r over its live edges: scalar loop over the non-empty
+// bitmap words, lane = bit; the loads of successive words do not depend on each
+// other and stay in flight together (measured faster than expanding the columns
+// into LDS first).
+__device__ __forceinline__ void rescan_row(int r, int n, int nw, int lane, const unsigned long long* __restrict__ LV,
+                                           const IcPair* __restrict__ IC, unsigned long long* kF_out, unsigned long long* kP_out) {
+  const unsigned long long bmw = lane < nw ? LV[(size_t)r * nw + lane] : 0ull;
+  unsigned long long todo = __ballot(bmw != 0ull);
+  unsigned long long kF = 0, kP = 0;
+  while (todo != 0ull) {
+    const int l = __builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    const unsigned long long w = readlane_u64(bmw, l);
+    if ((w >> lane) & 1ull) {
+      const int b = (l << 6) + lane;
+      const IcPair v = IC[ic_index(r, b, n)];
+      const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
+      kF = k1 > kF ? k1 : kF;
+      kP = k2 > kP ? k2 : kP;
+    }
+  }
+  *kF_out = wave_max_u64(kF);
+  *kP_out = wave_max_u64(kP);
+}
+
 struct GreaterCnt {  // cmp() of the reference, :699-701: coverage descending
   __host__ __device__ bool operator()(unsigned int x, unsigned int y) const { return (x >> 16) > (y >> 16); }
 };
@@ -362,12 +387,21 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             const int b = nbr[i];
             const int wab = Wm[(size_t)a * n + b];
             long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
-            for (int wi = 0; wi < deg; wi++) {
-              const int w = nbr[wi];
-              const int waw = Wm[(size_t)a * n + w];  // wave-uniform
-              const int wwb = Wm[(size_t)w * n + b];
-              f += icf_term(waw, wwb);
-              p += icp_term(waw, wwb);
+            // eight triangles per trip: their sixteen loads are independent and in
+            // flight together (a one-load-per-trip loop here is pure HBM/L2 latency)
+            for (int w0 = 0; w0 < deg; w0 += 8) {
+              int wa[8], wb[8];
+#pragma unroll
+              for (int c = 0; c < 8; c++) {
+                const int w = nbr[w0 + c < deg ? w0 + c : 0];
+                wa[c] = w0 + c < deg ? Wm[(size_t)a * n + w] : 0;  // wave-uniform
+                wb[c] = w0 + c < deg ? Wm[(size_t)w * n + b] : 0;
+              }
+#pragma unroll
+              for (int c = 0; c < 8; c++) {
+                f += icf_term(wa[c], wb[c]);
+                p += icp_term(wa[c], wb[c]);
+              }
             }
             if (a < b) {
               IcPair v;
@@ -465,25 +499,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           const int nd = s_nd;
           for (int di = wv; di < nd; di += 4) {
             const int r = dlist[di];
-            // live columns word by word (scalar loop over the non-empty words); the
-            // loads of all words are in flight together, consumed by the max below
-            const unsigned long long bmw = lane < nw ? LV[(size_t)r * nw + lane] : 0ull;
-            unsigned long long todo = __ballot(bmw != 0ull);
-            unsigned long long kF = 0, kP = 0;
-            while (todo != 0ull) {
-              const int l = __builtin_ctzll(todo);
-              todo &= todo - 1ull;
-              const unsigned long long w = readlane_u64(bmw, l);
-              if ((w >> lane) & 1ull) {
-                const int b = (l << 6) + lane;
-                const IcPair v = IC[ic_index(r, b, n)];
-                const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
-                kF = k1 > kF ? k1 : kF;
-                kP = k2 > kP ? k2 : kP;
-              }
-            }
-            kF = wave_max_u64(kF);
-            kP = wave_max_u64(kP);
+            unsigned long long kF, kP;
+            rescan_row(r, n, nw, lane, LV, IC, &kF, &kP);
             if (lane == 0) {
               bestF[r] = kF;
               bestP[r] = kP;
@@ -812,23 +829,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         const int nd = s_nd;
         for (int di = wv; di < nd; di += 4) {
           const int r = dlist[di];
-          const unsigned long long bmw = lane < nw ? LV[(size_t)r * nw + lane] : 0ull;
-          unsigned long long todo = __ballot(bmw != 0ull);
-          unsigned long long kF = 0, kP = 0;
-          while (todo != 0ull) {
-            const int l = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const unsigned long long w = readlane_u64(bmw, l);
-            if ((w >> lane) & 1ull) {
-              const int b = (l << 6) + lane;
-              const IcPair v = IC[ic_index(r, b, n)];
-              const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
-              kF = k1 > kF ? k1 : kF;
-              kP = k2 > kP ? k2 : kP;
-            }
-          }
-          kF = wave_max_u64(kF);
-          kP = wave_max_u64(kP);
+          unsigned long long kF, kP;
+          rescan_row(r, n, nw, lane, LV, IC, &kF, &kP);
           if (lane == 0) {
             bestF[r] = kF;
             bestP[r] = kP;
