@@ -34,13 +34,18 @@ __device__ __forceinline__ bool tba_test(const unsigned int* tba, int k) {
 // is outside the alignment loop in the reference (:98-106, :214-222), so the
 // lowest allele any alignment of that name matches wins, and among those the
 // earliest alignment created the Read (its identity becomes the Read's mapq).
+// mapq_gt: only alignments with read_mapq > mapq_gt count (-1 = all).  S2 adds a
+// variant to an EXISTING read only if `alignment.id*100 > 90` (:245); the variant
+// that creates the read is exempt.
 __device__ __forceinline__ int merged_allele(const signed char* __restrict__ v, long long R, int k,
                                              const long long* __restrict__ name_off,
-                                             const int* __restrict__ name_aln, int g, int* creator) {
+                                             const int* __restrict__ name_aln, int g, int* creator,
+                                             const int* __restrict__ mapq = nullptr, int mapq_gt = -1) {
   int best_a = 127, best_r = -1;
   for (long long ai = name_off[g]; ai < name_off[g + 1]; ai++) {
     int r = name_aln[ai];
     int a = v[(long long)k * R + r];
+    if (mapq_gt >= 0 && mapq[r] <= mapq_gt) continue;
     if (a >= 0 && a < best_a) {
       best_a = a;
       best_r = r;
@@ -66,7 +71,9 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
   unsigned int* srt = keys + lds.maxG;     // [maxG]
   unsigned short* kname = (unsigned short*)(srt + lds.maxG);  // [maxG]
   unsigned short* insname = kname + lds.maxG;                 // [maxG]
-  unsigned short* cidx = insname + lds.maxG;                  // [maxB+1]
+  unsigned short* kfirst = insname + lds.maxG;                // [maxG]
+  unsigned short* insfirst = kfirst + lds.maxG;               // [maxG]
+  unsigned short* cidx = insfirst + lds.maxG;                 // [maxB+1]
   __shared__ int s_maxpos, s_any, s_n, s_P;
 
   if (tid < 32) { tba[tid] = 0; firsts[tid] = 0; lasts[tid] = 0; posm[tid] = 0; }
@@ -170,12 +177,14 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
   __syncthreads();
 
   // ---- phase C: S2 variants restricted to to_be_added, S2b filter ----------
+  const int* mq = db.read_mapq + m.r0;
   for (int g = tid; g < G; g += kBlock) {
     int nvar = 0, first = -1, afirst = 0, rcre = 0, mapq = -1;
     for (int k = 0; k < B; k++) {
       if (!tba_test(tba, k)) continue;
       int cr;
-      int a = merged_allele(vpart, R, k, name_off, name_aln, g, &cr);
+      // the first hit creates the Read (any identity); later positions need > 90
+      int a = merged_allele(vpart, R, k, name_off, name_aln, g, &cr, mq, first < 0 ? -1 : 90);
       if (a < 0) continue;
       nvar++;
       if (first < 0) { first = k; afirst = a; rcre = cr; mapq = db.read_mapq[m.r0 + cr]; }
@@ -185,10 +194,12 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
       // creation order of the Read objects in partial_readset: (position, allele, alignment)
       keys[slot] = ((unsigned)first << 21) | ((unsigned)afirst << 17) | (unsigned)rcre;
       kname[slot] = (unsigned short)g;
-      for (int k = 0; k < B; k++) {
+      kfirst[slot] = (unsigned short)first;
+      for (int k = first; k < B; k++) {
         if (!tba_test(tba, k)) continue;
         int cr;
-        if (merged_allele(vpart, R, k, name_off, name_aln, g, &cr) >= 0) atomicOr(&posm[k >> 5], 1u << (k & 31));
+        if (merged_allele(vpart, R, k, name_off, name_aln, g, &cr, mq, k == first ? -1 : 90) >= 0)
+          atomicOr(&posm[k >> 5], 1u << (k & 31));
       }
     }
   }
@@ -210,6 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
     for (int j = 0; j < n; j++) rank += (keys[j] < ki) ? 1 : 0;
     srt[rank] = ((ki >> 21) << 16) | (unsigned)rank;
     insname[rank] = kname[i];
+    insfirst[rank] = kfirst[i];
   }
   if (tid == 0) {
     int P = 0;
@@ -231,6 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
   const int Wp = (P + 63) >> 6;
   for (int i = tid; i < n; i += kBlock) {
     const int g = insname[srt[i] & 0xffffu];
+    const int gfirst = insfirst[srt[i] & 0xffffu];
     db.fr_name[m.fr0 + i] = g;
     unsigned long long cw = 0, pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0;
     int curw = 0;
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
         if (!((posm[k >> 5] >> (k & 31)) & 1u)) continue;
         j = cidx[k];
         int cr;
-        a = merged_allele(vpart, R, k, name_off, name_aln, g, &cr);
+        a = k < gfirst ? -1 : merged_allele(vpart, R, k, name_off, name_aln, g, &cr, mq, k == gfirst ? -1 : 90);
       }
       const int wj = (k < B) ? (j >> 6) : Wp;  // k == B flushes the tail
       while (curw < wj) {
@@ -274,7 +287,7 @@ size_t readset_lds_bytes(const ReadsetLds& l) {
   size_t b = (size_t)l.wordsN * kBlock * 8;   // bitsets
   b += 4 * 32 * 4;                            // tba, firsts, lasts, posm
   b += (size_t)l.maxG * 4 * 2;                // keys, srt
-  b += (size_t)l.maxG * 2 * 2;                // kname, insname
+  b += (size_t)l.maxG * 2 * 4;                // kname, insname, kfirst, insfirst
   b += (size_t)(l.maxB + 2) * 2;              // cidx
   return (b + 15) & ~(size_t)15;
 }

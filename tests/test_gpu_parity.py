@@ -221,3 +221,13 @@ def test_c3_full_size_properties():
         o = ob.phase_batch(capi.synth_batch(**sub), capi.default_params())
         np.testing.assert_array_equal(o.chain_haps(0), g.chain_haps(c))
         assert o.n_iterations[0] == g.n_iterations[c]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_irregular_batches(seed):
+    """differential fuzz: irregular bubbles (1..5 alleles, 2..5-node paths in either
+    direction), reads with foreign / repeated nodes, repeated names"""
+    from random_batches import random_batch
+
+    b = random_batch(1000 + seed)
+    _compare(b, capi.default_params(want_stages=1, min_mapq=93 if seed % 2 else 90))
