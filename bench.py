@@ -185,9 +185,10 @@ def main():
 
 def pmc_traffic(config, chains):
     """HBM bytes of one k_phase launch from the committed rocprofv3 PMC summary
-    (FETCH_SIZE + WRITE_SIZE, tools/pmc.sh) of this very workload; None if the
-    summary is for another workload.  Raw counter sum: FETCH_SIZE is uncalibrated
-    for k_phase's scattered reads (profiles/*pmc_hbm.json gives both readings)."""
+    (tools/pmc.sh, separate FETCH_SIZE / WRITE_SIZE passes) of this very workload;
+    None if the summary is for another workload.  (2*FETCH_SIZE + WRITE_SIZE)*1024:
+    the gfx950 half-count of FETCH_SIZE was calibrated on scattered 4- and 16-byte
+    reads as well (profiles/r01_fetch_calibration.json): 64 B tallied per request."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
     for f in reversed(files):
@@ -196,7 +197,7 @@ def pmc_traffic(config, chains):
         except Exception:
             continue
         if d.get("config") == config and d.get("chains") == chains:
-            return d["kernels"]["k_phase"]["hbm_bytes_raw"]
+            return d["kernels"]["k_phase"]["hbm_bytes_fetch_x2"]
     return None
 
 
