@@ -125,10 +125,12 @@ __device__ __forceinline__ int new_w(int r1, int r2, bool merge) {
 }
 
 
-// induced costs are stored once per edge, at [min(a,b)][max(a,b)]
-__device__ __forceinline__ size_t ic_index(int a, int b, int n) {
-  return a < b ? (size_t)a * n + b : (size_t)b * n + a;
-}
+// Induced costs are stored for both orientations of an edge: every read of row
+// r touches IC[r][.] only (neighbours of a read cluster in a few 128-B lines),
+// and only the few edges that actually change (~8 % of the candidates) pay for
+// the second, scattered store.  (A single copy at [min][max] made half of all
+// reads column accesses: one HBM line per 16 useful bytes.)
+__device__ __forceinline__ size_t ic_index(int r, int c, int n) { return (size_t)r * n + c; }
 
 // Exact maximum of row r over its live edges: scalar loop over the non-empty
 // bitmap words, lane = bit; the loads of successive words do not depend on each
@@ -403,12 +405,10 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
                 p += icp_term(wa[c], wb[c]);
               }
             }
-            if (a < b) {
-              IcPair v;
-              v.f = f;
-              v.p = p;
-              IC[(size_t)a * n + b] = v;
-            }
+            IcPair v;
+            v.f = f;
+            v.p = p;
+            IC[(size_t)a * n + b] = v;
             const unsigned long long k1 = mkkey(f, b), k2 = mkkey(p, b);
             kF = k1 > kF ? k1 : kF;
             kP = k2 > kP ? k2 : kP;
@@ -699,7 +699,10 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           const int rx = (int)(it >> 28), rb = (int)((it >> 24) & 7u);
           const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
           const size_t ici = ic_index(x, b, n);
-          IcPair ic = IC[ici];  // issued before the triangle loads, used after them
+          // speculative: only ~8 % of the candidates change, but loading the entry
+          // after the triangle terms (a dependent load) measured 4 % slower although it
+          // cuts the loop's HBM lines by a quarter -- the loop is latency-bound
+          IcPair ic = IC[ici];
           long long df = 0, dp = 0;
 #ifdef AHK_TIMING
           AHK_T(8);
@@ -763,6 +766,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           ic.f += df;
           ic.p += dp;
           IC[ici] = ic;
+          IC[ic_index(b, x, n)] = ic;
 #ifdef AHK_TIMING
           atomicAdd(&s_chg, 1);
 #endif
