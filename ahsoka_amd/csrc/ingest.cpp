@@ -29,7 +29,10 @@
 #include <map>
 #include <new>
 #include <set>
+#include <cerrno>
 #include <sstream>
+#include <string_view>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -254,52 +257,141 @@ struct Graph {
   }
 };
 
-struct GafLine {
-  std::string name;
-  float identity;
-  std::vector<int> node_ids;
+// All GAF lines, parsed.  The file is read into memory once and tokenised in
+// place by several threads (chunks cut at line ends, results concatenated in
+// file order); names are views into the buffer, node ids go to one flat pool.
+// Semantics follow AlignmentReader::readAlignmentfile (src/alignmentreader.cpp:
+// 69-186): a line is what getline returns before EOF is hit (an unterminated
+// last line is dropped, :80), empty lines are skipped, fields are the first 16
+// whitespace-separated tokens, token 16 is id:<..>:<float>.
+struct GafTable {
+  std::string buf;
+  std::vector<uint64_t> name_off;
+  std::vector<uint32_t> name_len;
+  std::vector<float> identity;
+  std::vector<uint64_t> node_off{0};
+  std::vector<int> nodes;
+  size_t size() const { return identity.size(); }
+  std::string_view name(size_t i) const { return std::string_view(buf.data() + name_off[i], name_len[i]); }
 };
 
-int read_gaf(const char* path, std::vector<GafLine>* out) {
-  std::ifstream f(path);
-  if (!f) return AHSOKA_E_IO;
-  std::string line;
-  while (std::getline(f, line)) {
-    if (!f.good()) break;
-    if (line.empty()) continue;
-    std::stringstream ss(line);
-    std::string tok[16];
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+// std::stoi / std::stof accept a prefix and throw when nothing converts
+inline bool parses_as_int(const char* b, const char* e) {
+  std::string t(b, e);
+  char* end = nullptr;
+  errno = 0;
+  long v = std::strtol(t.c_str(), &end, 10);
+  return end != t.c_str() && errno != ERANGE && v >= INT32_MIN && v <= INT32_MAX;
+}
+
+struct GafChunk {
+  std::vector<uint64_t> name_off;
+  std::vector<uint32_t> name_len;
+  std::vector<float> identity;
+  std::vector<uint32_t> node_cnt;
+  std::vector<int> nodes;
+  int err = AHSOKA_OK;
+};
+
+void parse_gaf_chunk(const std::string& buf, size_t beg, size_t end, GafChunk* out) {
+  const char* base = buf.data();
+  size_t pos = beg;
+  while (pos < end) {
+    const char* nl = (const char*)std::memchr(base + pos, '\n', end - pos);
+    if (!nl) break;  // unterminated tail: dropped, like the reference
+    const char* lb = base + pos;
+    const char* le = nl;
+    pos = (size_t)(nl - base) + 1;
+    if (le == lb) continue;
+    const char* tb[16];
+    const char* te[16];
     int nt = 0;
-    while (nt < 16 && (ss >> tok[nt])) nt++;
-    if (nt < 16) return AHSOKA_E_PARSE;
-    // token 16: "id:f:<float>" -- split on ':', first field must be "id", value is the last
-    const std::string& idtok = tok[15];
-    size_t c1 = idtok.find(':');
-    if (c1 == std::string::npos || idtok.substr(0, c1) != "id") return AHSOKA_E_PARSE;
-    size_t cl = idtok.rfind(':');
-    GafLine gl;
-    try {
-      gl.identity = std::stof(idtok.substr(cl + 1));
-      (void)std::stoi(tok[7]);
-      (void)std::stoi(tok[8]);
-    } catch (...) {
-      return AHSOKA_E_PARSE;
+    const char* q = lb;
+    while (nt < 16) {
+      while (q < le && is_ws(*q)) q++;
+      if (q >= le) break;
+      tb[nt] = q;
+      while (q < le && !is_ws(*q)) q++;
+      te[nt] = q;
+      nt++;
     }
-    gl.name = tok[0];
-    const std::string& p = tok[5];
-    size_t pos = 0;
-    while (pos < p.size()) {
-      while (pos < p.size() && (p[pos] == '<' || p[pos] == '>')) pos++;
-      size_t beg = pos;
-      while (pos < p.size() && p[pos] != '<' && p[pos] != '>') pos++;
-      if (pos > beg) {
-        bool ok = true;
-        int id = digits_of(p.substr(beg, pos - beg), &ok);
-        if (!ok) return AHSOKA_E_PARSE;
-        gl.node_ids.push_back(id);
+    if (nt < 16) { out->err = AHSOKA_E_PARSE; return; }
+    // token 16: first ':'-field must be "id", the value follows the last ':'
+    const char* c1 = (const char*)std::memchr(tb[15], ':', (size_t)(te[15] - tb[15]));
+    if (!c1 || c1 - tb[15] != 2 || tb[15][0] != 'i' || tb[15][1] != 'd') { out->err = AHSOKA_E_PARSE; return; }
+    const char* cl = te[15];
+    while (cl > tb[15] && cl[-1] != ':') cl--;
+    {
+      std::string t(cl, te[15]);
+      char* endp = nullptr;
+      errno = 0;
+      const float v = std::strtof(t.c_str(), &endp);
+      if (endp == t.c_str() || errno == ERANGE) { out->err = AHSOKA_E_PARSE; return; }
+      out->identity.push_back(v);
+    }
+    if (!parses_as_int(tb[7], te[7]) || !parses_as_int(tb[8], te[8])) { out->err = AHSOKA_E_PARSE; return; }
+    out->name_off.push_back((uint64_t)(tb[0] - base));
+    out->name_len.push_back((uint32_t)(te[0] - tb[0]));
+    // path: maximal runs without '<' / '>'; a node id is the digits of the run
+    uint32_t cnt = 0;
+    const char* r = tb[5];
+    while (r < te[5]) {
+      while (r < te[5] && (*r == '<' || *r == '>')) r++;
+      const char* rb = r;
+      while (r < te[5] && *r != '<' && *r != '>') r++;
+      if (r > rb) {
+        long long id = 0;
+        int nd = 0;
+        for (const char* d = rb; d < r; d++)
+          if (*d >= '0' && *d <= '9') { id = id * 10 + (*d - '0'); nd++; }
+        if (nd == 0 || nd > 9) { out->err = AHSOKA_E_PARSE; return; }
+        out->nodes.push_back((int)id);
+        cnt++;
       }
     }
-    out->push_back(std::move(gl));
+    out->node_cnt.push_back(cnt);
+  }
+}
+
+int read_gaf(const char* path, GafTable* out) {
+  {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return AHSOKA_E_IO;
+    f.seekg(0, std::ios::end);
+    const std::streamoff sz = f.tellg();
+    f.seekg(0, std::ios::beg);
+    out->buf.resize((size_t)std::max<std::streamoff>(sz, 0));
+    if (sz > 0) f.read(&out->buf[0], sz);
+  }
+  const std::string& buf = out->buf;
+  unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (buf.size() < (1u << 20)) nthr = 1;
+  std::vector<size_t> cut(nthr + 1, buf.size());
+  cut[0] = 0;
+  for (unsigned t = 1; t < nthr; t++) {
+    size_t p = buf.size() / nthr * t;
+    const char* nl = (const char*)std::memchr(buf.data() + p, '\n', buf.size() - p);
+    cut[t] = nl ? (size_t)(nl - buf.data()) + 1 : buf.size();
+  }
+  for (unsigned t = 1; t <= nthr; t++) cut[t] = std::max(cut[t], cut[t - 1]);
+  std::vector<GafChunk> chunks(nthr);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nthr; t++) th.emplace_back(parse_gaf_chunk, std::cref(buf), cut[t], cut[t + 1], &chunks[t]);
+  for (auto& x : th) x.join();
+  for (auto& c : chunks)
+    if (c.err) return c.err;  // the reference aborts at the first malformed line
+  size_t nl = 0, nn = 0;
+  for (auto& c : chunks) { nl += c.identity.size(); nn += c.nodes.size(); }
+  out->name_off.reserve(nl); out->name_len.reserve(nl); out->identity.reserve(nl);
+  out->node_off.reserve(nl + 1); out->nodes.reserve(nn);
+  for (auto& c : chunks) {
+    out->name_off.insert(out->name_off.end(), c.name_off.begin(), c.name_off.end());
+    out->name_len.insert(out->name_len.end(), c.name_len.begin(), c.name_len.end());
+    out->identity.insert(out->identity.end(), c.identity.begin(), c.identity.end());
+    for (uint32_t k : c.node_cnt) out->node_off.push_back(out->node_off.back() + k);
+    out->nodes.insert(out->nodes.end(), c.nodes.begin(), c.nodes.end());
   }
   return AHSOKA_OK;
 }
@@ -315,7 +407,7 @@ extern "C" int ahsoka_ingest_dump(const char* gfa_path, const char* gaf_path, co
     Graph g;
     if (int e = g.read_gfa(gfa_path)) return e;
     g.find_chains();
-    std::vector<GafLine> gaf;
+    GafTable gaf;
     if (gaf_path && *gaf_path)
       if (int e = read_gaf(gaf_path, &gaf)) return e;
     FILE* f = std::fopen(out_path, "w");
@@ -353,15 +445,17 @@ extern "C" int ahsoka_ingest_dump(const char* gfa_path, const char* gaf_path, co
     std::map<int, std::vector<std::pair<int, int>>> per_chain;  // chain -> (line, copies)
     for (size_t li = 0; li < gaf.size(); li++) {
       std::map<int, int> cnt;
-      for (int nid : gaf[li].node_ids) cnt[chain_of(nid)]++;
+      for (uint64_t e = gaf.node_off[li]; e < gaf.node_off[li + 1]; e++) cnt[chain_of(gaf.nodes[e])]++;
       for (auto& kv : cnt) per_chain[kv.first].emplace_back((int)li, kv.second);
     }
     for (auto& kv : per_chain)
       for (auto& lc : kv.second) {
-        const GafLine& gl = gaf[(size_t)lc.first];
-        const float scaled = gl.identity * 100;
-        std::fprintf(f, "ALN %d %s %d %d %zu", kv.first, gl.name.c_str(), (int)scaled, lc.second, gl.node_ids.size());
-        for (int nd : gl.node_ids) std::fprintf(f, " %d", nd);
+        const size_t li = (size_t)lc.first;
+        const float scaled = gaf.identity[li] * 100;
+        const std::string nm(gaf.name(li));
+        std::fprintf(f, "ALN %d %s %d %d %zu", kv.first, nm.c_str(), (int)scaled, lc.second,
+                     (size_t)(gaf.node_off[li + 1] - gaf.node_off[li]));
+        for (uint64_t e = gaf.node_off[li]; e < gaf.node_off[li + 1]; e++) std::fprintf(f, " %d", gaf.nodes[e]);
         std::fprintf(f, "\n");
       }
     std::fprintf(f, "ORDER");
@@ -382,7 +476,7 @@ extern "C" int ahsoka_ingest(const char* gfa_path, const char* gaf_path, ahsoka_
     Graph g;
     if (int e = g.read_gfa(gfa_path)) return e;
     g.find_chains();
-    std::vector<GafLine> gaf;
+    GafTable gaf;
     if (gaf_path && *gaf_path)
       if (int e = read_gaf(gaf_path, &gaf)) return e;
 
@@ -391,20 +485,27 @@ extern "C" int ahsoka_ingest(const char* gfa_path, const char* gaf_path, ahsoka_
     for (const GChain& ch : g.chains) order.emplace_back((int)ch.bubbles.size(), ch.id);
     std::sort(order.begin(), order.end(), std::greater<>());
 
-    // chain of every GAF node: nodes of no chain read as chain 0 (default chain_id)
-    auto chain_of = [&](int nid) {
-      auto it = g.nodes.find(nid);
-      return it == g.nodes.end() ? 0 : it->second.chain;
-    };
-    std::vector<std::vector<int>> lines_of_chain(g.chains.size());
-    for (size_t li = 0; li < gaf.size(); li++) {
+    // chain of every node id as a dense table: nodes of no chain (and ids the graph
+    // does not know) read as chain 0, the reference's default chain_id
+    int max_id = 0;
+    for (auto& kv : g.nodes) max_id = std::max(max_id, kv.first);
+    for (int nid : gaf.nodes) max_id = std::max(max_id, nid);
+    std::vector<int> chain_tab((size_t)max_id + 1, 0);
+    for (auto& kv : g.nodes)
+      if (kv.first >= 0) chain_tab[(size_t)kv.first] = kv.second.chain;
+    const int nchains = (int)g.chains.size();
+    // lines of every chain, in file order (a line is filed once per chain it touches)
+    std::vector<std::vector<uint32_t>> lines_of_chain((size_t)nchains);
+    {
       std::vector<int> touched;
-      for (int nid : gaf[li].node_ids) {
-        int c = chain_of(nid);
-        if (c >= 0 && c < (int)g.chains.size() && std::find(touched.begin(), touched.end(), c) == touched.end())
-          touched.push_back(c);
+      for (size_t li = 0; li < gaf.size(); li++) {
+        touched.clear();
+        for (uint64_t e = gaf.node_off[li]; e < gaf.node_off[li + 1]; e++) {
+          const int c = chain_tab[(size_t)gaf.nodes[e]];
+          if (c >= 0 && c < nchains && std::find(touched.begin(), touched.end(), c) == touched.end()) touched.push_back(c);
+        }
+        for (int c : touched) lines_of_chain[(size_t)c].push_back((uint32_t)li);
       }
-      for (int c : touched) lines_of_chain[c].push_back((int)li);
     }
 
     ahk::HostBatch* hb = new ahk::HostBatch();
@@ -415,17 +516,19 @@ extern "C" int ahsoka_ingest(const char* gfa_path, const char* gaf_path, ahsoka_
     hb->node_off.push_back(0);
     hb->read_off.push_back(0);
     hb->rnode_off.push_back(0);
+    // chain-local index of a node id: dense table + "which chain wrote it" stamp
+    std::vector<int> loc_idx((size_t)max_id + 1, -1), loc_stamp((size_t)max_id + 1, -1);
+    int stamp = 0;
     for (auto& oc : order) {
       const GChain& ch = g.chains[(size_t)oc.second];
       hb->chain_id.push_back(ch.id);
-      std::unordered_map<int, int> local;
+      int nlocal = 0;
       auto local_of = [&](int nid) {
-        auto it = local.find(nid);
-        if (it != local.end()) return it->second;
-        int idx = (int)local.size();
-        local[nid] = idx;
+        if (loc_stamp[(size_t)nid] == stamp) return loc_idx[(size_t)nid];
+        loc_stamp[(size_t)nid] = stamp;
+        loc_idx[(size_t)nid] = nlocal;
         hb->node_id.push_back(nid);
-        return idx;
+        return nlocal++;
       };
       for (const GBubble& b : ch.bubbles) {
         local_of(b.source);
@@ -444,20 +547,21 @@ extern "C" int ahsoka_ingest(const char* gfa_path, const char* gaf_path, ahsoka_
       }
       hb->bubble_off.push_back((int64_t)hb->allele_off.size() - 1);
       hb->node_off.push_back((int64_t)hb->node_id.size());
-      std::unordered_map<std::string, int> name_id;
-      for (int li : lines_of_chain[(size_t)ch.id]) {
-        const GafLine& gl = gaf[(size_t)li];
-        for (int nid : gl.node_ids) {
-          auto it = local.find(nid);
-          hb->rnode.push_back(it == local.end() ? -1 : it->second);
+      std::unordered_map<std::string_view, int> name_id;
+      name_id.reserve(lines_of_chain[(size_t)ch.id].size() * 2);
+      for (uint32_t li : lines_of_chain[(size_t)ch.id]) {
+        for (uint64_t e = gaf.node_off[li]; e < gaf.node_off[li + 1]; e++) {
+          const int nid = gaf.nodes[e];
+          hb->rnode.push_back(loc_stamp[(size_t)nid] == stamp ? loc_idx[(size_t)nid] : -1);
         }
         hb->rnode_off.push_back((int64_t)hb->rnode.size());
-        const float scaled = gl.identity * 100;  // float multiply, then the implicit float->int of the Read ctor
+        const float scaled = gaf.identity[li] * 100;  // float multiply, then the implicit float->int of the Read ctor
         hb->read_mapq.push_back((int32_t)scaled);
-        auto ins = name_id.emplace(gl.name, (int)name_id.size());
+        auto ins = name_id.emplace(gaf.name(li), (int)name_id.size());
         hb->read_name.push_back(ins.first->second);
       }
       hb->read_off.push_back((int64_t)hb->read_mapq.size());
+      stamp++;
     }
     hb->finish();
     *out = &hb->view;
