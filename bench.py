@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", help="BASELINE config (c3 = headline); others for experiments")
     ap.add_argument("--chains", type=int, default=0, help="override chains per GPU (experiments only)")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="chains timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=24, help="chains timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -231,3 +231,34 @@ def test_random_irregular_batches(seed):
 
     b = random_batch(1000 + seed)
     _compare(b, capi.default_params(want_stages=1, min_mapq=93 if seed % 2 else 90))
+
+
+@pytest.mark.parametrize("over", [
+    dict(min_overlap=2), dict(min_variants=3), dict(switch_cost=5.0, affine_switch_cost=1.0),
+    dict(min_mapq=96), dict(switch_cost=0.0, affine_switch_cost=0.0),
+])
+def test_parameters_are_honoured(over):
+    """the reference's literals are parameters of the ABI: non-default values"""
+    b = capi.synth_batch(n_chains=5, n_bubbles=16, n_reads=220, seed=31, allele_err=0.06)
+    _compare(b, capi.default_params(want_stages=1, **over))
+
+
+def test_cli_end_to_end(tmp_path):
+    """`Ahsoka phase -g .. -a .. -o ..` (the reference's command line) writes the same
+    haplotype text as rendering the library result"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ahsoka_amd", "Ahsoka")
+    gold = os.path.join(root, "tests", "golden")
+    prefix = str(tmp_path / "out")
+    subprocess.run([exe, "phase", "-g", os.path.join(gold, "c1.gfa"), "-a", os.path.join(gold, "c1.gaf"), "-o", prefix],
+                   check=True, capture_output=True)
+    b = capi.ingest(os.path.join(gold, "c1.gfa"), os.path.join(gold, "c1.gaf"))
+    g = capi.phase_batch(b)
+    expect = "".join(capi.render_chain(b, g, c) for c in range(b.n_chains))
+    assert open(prefix + "-result.txt").read() == expect
+    assert open(prefix + "-bubbleinfo.txt").read().startswith("chain id: 0size: 5\nbubble id: 0\nnode id: 160,158,159,157,\n")
+    # per-chain files hold the node lines only (src/alignmentstoreadset.cpp:411-412,449,456)
+    lines = open(prefix + "-chain9-result.txt").read().split("\n")
+    assert len(lines) == 3 and lines[0].endswith("),") and lines[2] == ""
