@@ -713,11 +713,11 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             const unsigned short* L2 = rx == ROLE_A ? listFb : listFa;
             const int n2 = rx == ROLE_A ? nFb : (rx == ROLE_B ? nFa : 0);
             const int nc = n1 + n2;
-            for (int w0 = 0; w0 < nc; w0 += 8) {
+            for (int w0 = 0; w0 < nc; w0 += 4) {
               // the sixteen loads of a chunk of eight triangles are independent
-              int ws4[8], ov4[8], wb4[8];
+              int ws4[4], ov4[4], wb4[4];
 #pragma unroll
-              for (int c = 0; c < 8; c++) {
+              for (int c = 0; c < 4; c++) {
                 const int wi = w0 + c;
                 const int w = wi < n1 ? L1[wi] : (wi < nc ? L2[wi - n1] : -1);
                 ws4[c] = w;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
                 wb4[c] = w >= 0 ? Wm[(size_t)w * n + b] : 0;
               }
 #pragma unroll
-              for (int c = 0; c < 8; c++) {
+              for (int c = 0; c < 4; c++) {
                 const int w = ws4[c];
                 if (w < 0) continue;
                 // the role of w follows from the list it sits in
