@@ -107,7 +107,7 @@ ABI_SYMBOLS = [
     "ahsoka_default_params", "ahsoka_backend_info", "ahsoka_abi_version", "ahsoka_phase_batch",
     "ahsoka_result_free", "ahsoka_batch_upload", "ahsoka_phase_device", "ahsoka_batch_download",
     "ahsoka_batch_free", "ahsoka_batch_kernel_times", "ahsoka_batch_bytes", "ahsoka_render_chain",
-    "ahsoka_ingest", "ahsoka_ingest_dump", "ahsoka_batch_host_free", "ahsoka_synth_batch", "ahsoka_synth_write_text",
+    "ahsoka_ingest", "ahsoka_ingest_dump", "ahsoka_batch_host_free", "ahsoka_synth_batch", "ahsoka_synth_write_text", "ahsoka_synth_truth",
     "ahsoka_test_introsort_u32", "ahsoka_test_detlog",
 ]
 
@@ -147,6 +147,8 @@ def lib() -> C.CDLL:
     L.ahsoka_batch_host_free.restype = None
     L.ahsoka_synth_batch.argtypes = [C.POINTER(CSynthSpec), C.POINTER(C.POINTER(CChainBatch))]
     L.ahsoka_synth_write_text.argtypes = [C.POINTER(CSynthSpec), C.c_char_p, C.c_char_p]
+    L.ahsoka_synth_truth.argtypes = [C.POINTER(CSynthSpec), u8p, C.c_int64]
+    L.ahsoka_synth_truth.restype = C.c_int64
     L.ahsoka_test_introsort_u32.argtypes = [C.POINTER(C.c_uint32), C.c_int32]
     L.ahsoka_test_detlog.argtypes = [C.c_double]
     L.ahsoka_test_detlog.restype = C.c_double
@@ -291,6 +293,17 @@ def synth_batch(**kw) -> ChainBatch:
     out = C.POINTER(CChainBatch)()
     _check(lib().ahsoka_synth_batch(C.byref(spec), C.byref(out)), "ahsoka_synth_batch")
     return ChainBatch(cptr=out)
+
+
+def synth_truth(**kw) -> np.ndarray:
+    """Truth alleles of the synthetic workload, flat: per chain [ploidy][B]."""
+    spec = synth_spec(**kw)
+    need = lib().ahsoka_synth_truth(C.byref(spec), C.cast(None, u8p), 0)
+    if need < 0:
+        raise AhsokaError(int(need), "ahsoka_synth_truth")
+    buf = np.zeros(max(1, need), dtype=np.uint8)
+    lib().ahsoka_synth_truth(C.byref(spec), buf.ctypes.data_as(u8p), need)
+    return buf[:need]
 
 
 def synth_write_text(gfa: str, gaf: str, **kw) -> None:

@@ -173,6 +173,22 @@ extern "C" void ahsoka_batch_host_free(ahsoka_chain_batch* b) {
   delete reinterpret_cast<ahk::HostBatch*>(b);
 }
 
+// Truth haplotypes of the same workload: for every chain, ploidy rows of B alleles
+// (row-major, chains concatenated).  Lets tests measure how well the phasing
+// recovers what the reads were drawn from.  Returns the number of bytes needed.
+extern "C" int64_t ahsoka_synth_truth(const ahsoka_synth_spec* sp, uint8_t* out, int64_t cap) {
+  if (check_spec(sp)) return AHSOKA_E_ARG;
+  int64_t need = 0;
+  SynthChain ch;
+  for (int c = 0; c < sp->n_chains; c++) {
+    make_chain(*sp, (int64_t)sp->first_chain + c, ch);
+    const int64_t bytes = (int64_t)sp->ploidy * ch.B;
+    if (out && need + bytes <= cap) std::memcpy(out + need, ch.hap.data(), (size_t)bytes);
+    need += bytes;
+  }
+  return need;
+}
+
 // GFA + GAF text of the same workload (small configs; used to pin the ingest
 // against the reference's own parsers).  All S lines precede all L lines and
 // both directions of every link are written.

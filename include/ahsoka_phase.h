@@ -221,6 +221,9 @@ typedef struct ahsoka_synth_spec {
 int ahsoka_synth_batch(const ahsoka_synth_spec* spec, ahsoka_chain_batch** out);
 int ahsoka_synth_write_text(const ahsoka_synth_spec* spec, const char* gfa_path,
                             const char* gaf_path);
+/* truth haplotypes the reads were drawn from: per chain ploidy rows of B alleles,
+ * chains concatenated; returns the bytes needed (fills out if cap suffices) */
+int64_t ahsoka_synth_truth(const ahsoka_synth_spec* spec, uint8_t* out, int64_t cap);
 
 /* test hooks (host-only, no GPU): the device code's re-statement of the
  * libstdc++ introsort, run on the host, so it can be pinned against std::sort */

@@ -212,6 +212,16 @@ def test_c3_full_size_properties():
         comp += int((h[0] ^ h[1]).sum())
         tot += h.shape[1]
     assert comp / tot > 0.97
+    # the result is a correct phasing: against the haplotypes the reads were drawn
+    # from (2 % allele errors), best of the two global assignments per chain
+    truth = capi.synth_truth(**cfg)
+    ok = tot = 0
+    for c in range(0, 10000, 13):
+        t = truth[c * 100:(c + 1) * 100].reshape(2, 50)[:, g.chain_pos(c)]
+        h = g.chain_haps(c)
+        ok += max(int((h == t).all(axis=0).sum()), int((h == t[::-1]).all(axis=0).sum()))
+        tot += h.shape[1]
+    assert ok / tot > 0.99
     # oracle on every 400th chain (25 chains), bit-exact
     idx = list(range(0, 10000, 400))
     for c in idx:

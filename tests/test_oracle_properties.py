@@ -72,3 +72,34 @@ def test_duplicate_read_names_merge_into_one_read():
     fn = r.stages["fread_name"]
     assert len(set(fn.tolist())) == len(fn)
     assert r.n_reads[0] <= 29
+
+
+def _accuracy(res, truth, cfg):
+    """fraction of phased positions whose haplotype set equals the truth set, after the
+    best global assignment of predicted to true haplotypes per chain (ploidy 2: swap)"""
+    p, B = cfg["ploidy"], cfg["n_bubbles"]
+    ok = tot = 0
+    for c in range(cfg["n_chains"]):
+        t = truth[c * p * B:(c + 1) * p * B].reshape(p, B)
+        h = res.chain_haps(c)
+        pos = res.chain_pos(c)
+        if len(pos) == 0:
+            continue
+        tt = t[:, pos]
+        a = int((h == tt).all(axis=0).sum())
+        b = int((h == tt[::-1]).all(axis=0).sum())
+        ok += max(a, b)
+        tot += len(pos)
+    return ok / max(1, tot)
+
+
+def test_noisy_data_phasing_accuracy():
+    """The re-stated WhatsHap stages must actually phase: 2 % allele errors, 40x depth.
+    (The reference pipeline switches haplotypes freely between blocks; inside a chain
+    of overlapping reads the assignment has to follow the truth.)"""
+    cfg = dict(n_chains=12, n_bubbles=20, n_reads=300, ploidy=2, seed=2024)
+    b = capi.synth_batch(**cfg)
+    truth = capi.synth_truth(**cfg)
+    r = ob.phase_batch(b, n_threads=4)
+    assert (r.status == capi.ST_PHASED).all()
+    assert _accuracy(r, truth, cfg) > 0.95
