@@ -130,7 +130,7 @@ __device__ __forceinline__ int new_w(int r1, int r2, bool merge) {
 // and only the few edges that actually change (~8 % of the candidates) pay for
 // the second, scattered store.  (A single copy at [min][max] made half of all
 // reads column accesses: one HBM line per 16 useful bytes.)
-__device__ __forceinline__ size_t ic_index(int r, int c, int n) { return (size_t)r * n + c; }
+__device__ __forceinline__ unsigned ic_index(int r, int c, int n) { return (unsigned)(r * n + c); }
 
 // Exact maximum of row r over its live edges: scalar loop over the non-empty
 // bitmap words, lane = bit; the loads of successive words do not depend on each
@@ -138,7 +138,7 @@ __device__ __forceinline__ size_t ic_index(int r, int c, int n) { return (size_t
 // into LDS first).
 __device__ __forceinline__ void rescan_row(int r, int n, int nw, int lane, const unsigned long long* __restrict__ LV,
                                            const IcPair* __restrict__ IC, unsigned long long* kF_out, unsigned long long* kP_out) {
-  const unsigned long long bmw = lane < nw ? LV[(size_t)r * nw + lane] : 0ull;
+  const unsigned long long bmw = lane < nw ? LV[(unsigned)(r * nw + lane)] : 0ull;
   unsigned long long todo = __ballot(bmw != 0ull);
   unsigned long long kF = 0, kP = 0;
   while (todo != 0ull) {
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             q = quantise_score(t1 + t2);
           }
         }
-        Wm[(size_t)i * n + j] = q;
+        Wm[(unsigned)(i * n + j)] = q;
         if (m.dump0 >= 0) db.score_dump[m.dump0 + (size_t)i * n + j] = q;
       }
     }
@@ -373,13 +373,13 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         int deg = 0;
         for (int w0 = 0; w0 < n; w0 += 64) {
           const int w = w0 + lane;
-          const bool nz = w < n && Wm[(size_t)a * n + w] != 0;
+          const bool nz = w < n && Wm[(unsigned)(a * n + w)] != 0;
           const unsigned long long mk = __ballot(nz);
           if (nz) nbr[deg + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)w;
           deg += __popcll(mk);
           if (lane == 0) {
-            LV[(size_t)a * nw + (w0 >> 6)] = mk;
-            NZ[(size_t)a * nw + (w0 >> 6)] = mk;
+            LV[(unsigned)(a * nw + (w0 >> 6))] = mk;
+            NZ[(unsigned)(a * nw + (w0 >> 6))] = mk;
           }
         }
         unsigned long long kF = 0, kP = 0;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           const int i = i0 + lane;
           if (i < deg) {
             const int b = nbr[i];
-            const int wab = Wm[(size_t)a * n + b];
+            const int wab = Wm[(unsigned)(a * n + b)];
             long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
             // eight triangles per trip: their sixteen loads are independent and in
             // flight together (a one-load-per-trip loop here is pure HBM/L2 latency)
@@ -396,8 +396,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
 #pragma unroll
               for (int c = 0; c < 8; c++) {
                 const int w = nbr[w0 + c < deg ? w0 + c : 0];
-                wa[c] = w0 + c < deg ? Wm[(size_t)a * n + w] : 0;  // wave-uniform
-                wb[c] = w0 + c < deg ? Wm[(size_t)w * n + b] : 0;
+                wa[c] = w0 + c < deg ? Wm[(unsigned)(a * n + w)] : 0;  // wave-uniform
+                wb[c] = w0 + c < deg ? Wm[(unsigned)(w * n + b)] : 0;
               }
 #pragma unroll
               for (int c = 0; c < 8; c++) {
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             IcPair v;
             v.f = f;
             v.p = p;
-            IC[(size_t)a * n + b] = v;
+            IC[(unsigned)(a * n + b)] = v;
             const unsigned long long k1 = mkkey(f, b), k2 = mkkey(p, b);
             kF = k1 > kF ? k1 : kF;
             kP = k2 > kP ? k2 : kP;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           if (cz == cu) r = ROLE_A;
           else if (cz == cv) r = ROLE_B;
           else if (merge) {
-            const bool fa = Wm[(size_t)eu * n + z] == W_FORB, fb = Wm[(size_t)ev * n + z] == W_FORB;
+            const bool fa = Wm[(unsigned)(eu * n + z)] == W_FORB, fb = Wm[(unsigned)(ev * n + z)] == W_FORB;
             if (fa && !fb) r = ROLE_FA;
             if (fb && !fa) r = ROLE_FB;
           }
@@ -618,8 +618,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           }
           unsigned long long lvw = 0ull, nzw = 0ull;
           if (x >= 0 && wordok) {
-            lvw = LV[(size_t)x * nw + kw];
-            nzw = NZ[(size_t)x * nw + kw];
+            lvw = LV[(unsigned)(x * nw + kw)];
+            nzw = NZ[(unsigned)(x * nw + kw)];
           }
           // the role of x follows from which list it came from
           const int rx = xi < nA ? ROLE_A : xi < nA + nB ? ROLE_B : xi < nA + nB + nFa ? ROLE_FA : ROLE_FB;
@@ -643,8 +643,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           if (x >= 0 && wordok) {
             const unsigned long long lvn = lvw & ~D;
             const unsigned long long nzn = nzw | D;
-            if (lvn != lvw) LV[(size_t)x * nw + kw] = lvn;
-            if (nzn != nzw) NZ[(size_t)x * nw + kw] = nzn;
+            if (lvn != lvw) LV[(unsigned)(x * nw + kw)] = lvn;
+            if (nzn != nzw) NZ[(unsigned)(x * nw + kw)] = nzn;
             const int xw = x >> 6;
             const unsigned long long low = kw < xw ? ~0ull : (kw == xw ? ((1ull << (x & 63)) - 1ull) : 0ull);
             // columns with a non-zero third edge to some rewritten neighbour of x
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           const unsigned int it = i < cap ? items_lds[i] : items_glb[i - cap];
           const int rx = (int)(it >> 28), rb = (int)((it >> 24) & 7u);
           const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
-          const size_t ici = ic_index(x, b, n);
+          const unsigned ici = ic_index(x, b, n);
           // speculative: only ~8 % of the candidates change, but loading the entry
           // after the triangle terms (a dependent load) measured 4 % slower although it
           // cuts the loop's HBM lines by a quarter -- the loop is latency-bound
@@ -721,8 +721,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
                 const int wi = w0 + c;
                 const int w = wi < n1 ? L1[wi] : (wi < nc ? L2[wi - n1] : -1);
                 ws4[c] = w;
-                ov4[c] = w >= 0 ? Wm[(size_t)x * n + w] : 0;
-                wb4[c] = w >= 0 ? Wm[(size_t)w * n + b] : 0;
+                ov4[c] = w >= 0 ? Wm[(unsigned)(x * n + w)] : 0;
+                wb4[c] = w >= 0 ? Wm[(unsigned)(w * n + b)] : 0;
               }
 #pragma unroll
               for (int c = 0; c < 4; c++) {
@@ -752,8 +752,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
                 const int rw = role[w];
                 if (w == x || in_s(rx, rw, merge)) continue;  // (x,w) changes too: counted above
                 const int Nv = new_w(rb, rw, merge);
-                const int ov = Wm[(size_t)w * n + b];
-                const int xw = Wm[(size_t)x * n + w];
+                const int ov = Wm[(unsigned)(w * n + b)];
+                const int xw = Wm[(unsigned)(x * n + w)];
                 df += icf_term(Nv, xw) - icf_term(ov, xw);
                 dp += icp_term(Nv, xw) - icp_term(ov, xw);
               }
@@ -821,8 +821,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
               y = listFa[yi];
               N = W_FORB;
             }
-            Wm[(size_t)x * n + y] = N;
-            Wm[(size_t)y * n + x] = N;
+            Wm[(unsigned)(x * n + y)] = N;
+            Wm[(unsigned)(y * n + x)] = N;
           }
         }
         if (merge)
