@@ -367,26 +367,36 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     const int nwp_log = nw <= 8 ? 3 : nw <= 16 ? 4 : 5;
     const int nwp = 1 << nwp_log;
     const int RP = 64 >> nwp_log;  // rows a wave handles at once
+    // Each unordered pair {a,b} is computed once, by the wave of its lower end a
+    // (lanes = the neighbours b > a), and stored for both orientations; the row
+    // maxima are folded in with LDS atomics.  Halving the pairs halves the HBM
+    // lines of the W[w][b] gathers: this phase runs at ~80 % of the achievable
+    // HBM rate (the 190 neighbour rows of a read do not fit any cache share).
+    for (int u = tid; u < n; u += kBlock) { bestF[u] = 0ull; bestP[u] = 0ull; }
+    __syncthreads();
     {
-      unsigned short* nbr = rowbuf + (size_t)wv * nmax;
+      unsigned short* nbr = rowbuf + (size_t)wv * nmax;   // all neighbours of a
+      unsigned short* nhi = listA + (size_t)wv * nmax;    // the neighbours b > a (role lists are free here)
       for (int a = wv; a < n; a += 4) {
-        int deg = 0;
+        int deg = 0, dhi = 0;
         for (int w0 = 0; w0 < n; w0 += 64) {
           const int w = w0 + lane;
           const bool nz = w < n && Wm[(unsigned)(a * n + w)] != 0;
           const unsigned long long mk = __ballot(nz);
+          const unsigned long long mh = __ballot(nz && w > a);
           if (nz) nbr[deg + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)w;
+          if (nz && w > a) nhi[dhi + __popcll(mh & ((1ull << lane) - 1ull))] = (unsigned short)w;
           deg += __popcll(mk);
+          dhi += __popcll(mh);
           if (lane == 0) {
             LV[(unsigned)(a * nw + (w0 >> 6))] = mk;
             NZ[(unsigned)(a * nw + (w0 >> 6))] = mk;
           }
         }
-        unsigned long long kF = 0, kP = 0;
-        for (int i0 = 0; i0 < deg; i0 += 64) {
+        for (int i0 = 0; i0 < dhi; i0 += 64) {
           const int i = i0 + lane;
-          if (i < deg) {
-            const int b = nbr[i];
+          if (i < dhi) {
+            const int b = nhi[i];
             const int wab = Wm[(unsigned)(a * n + b)];
             long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
             // eight triangles per trip: their sixteen loads are independent and in
@@ -409,16 +419,12 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             v.f = f;
             v.p = p;
             IC[(unsigned)(a * n + b)] = v;
-            const unsigned long long k1 = mkkey(f, b), k2 = mkkey(p, b);
-            kF = k1 > kF ? k1 : kF;
-            kP = k2 > kP ? k2 : kP;
+            IC[(unsigned)(b * n + a)] = v;
+            atomicMax(&bestF[a], mkkey(f, b));
+            atomicMax(&bestP[a], mkkey(p, b));
+            atomicMax(&bestF[b], mkkey(f, a));
+            atomicMax(&bestP[b], mkkey(p, a));
           }
-        }
-        kF = wave_max_u64(kF);
-        kP = wave_max_u64(kP);
-        if (lane == 0) {
-          bestF[a] = kF;
-          bestP[a] = kP;
         }
       }
     }
