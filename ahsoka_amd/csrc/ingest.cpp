@@ -30,6 +30,7 @@
 #include <new>
 #include <set>
 #include <cerrno>
+#include <chrono>
 #include <sstream>
 #include <string_view>
 #include <thread>
@@ -88,34 +89,78 @@ struct Graph {
   std::unordered_map<Oriented, std::vector<Oriented>, OrientedHash> edges;
   std::vector<GChain> chains;
 
+  // The file is read once and tokenised in place (no per-line stream objects, the
+  // segment sequences are never copied); lines are applied in file order, which is
+  // what fixes the iteration order of `nodes` and with it every chain / bubble id.
   int read_gfa(const char* path) {
-    std::ifstream f(path);
-    if (!f) return AHSOKA_E_IO;
-    std::string line;
-    while (std::getline(f, line)) {
-      if (!f.good()) break;  // a last line without '\n' is dropped, as in the reference (:193)
-      if (line.empty()) continue;
-      if (line[0] == 'S') {
-        std::stringstream ss(line);
-        std::string tag, name, seq;
-        ss >> tag >> name >> seq;
+    std::string buf;
+    {
+      std::ifstream f(path, std::ios::binary);
+      if (!f) return AHSOKA_E_IO;
+      f.seekg(0, std::ios::end);
+      const std::streamoff sz = f.tellg();
+      f.seekg(0, std::ios::beg);
+      buf.resize((size_t)std::max<std::streamoff>(sz, 0));
+      if (sz > 0) f.read(&buf[0], sz);
+    }
+    auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
+    const char* p = buf.data();
+    const char* end = p + buf.size();
+    while (p < end) {
+      const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
+      if (!nl) break;  // a last line without '\n' is dropped, as in the reference (:193)
+      const char* lb = p;
+      const char* le = nl;
+      p = nl + 1;
+      if (le == lb || (lb[0] != 'S' && lb[0] != 'L')) continue;
+      const char* tb[7];
+      const char* te[7];
+      int nt = 0;
+      const char* q = lb;
+      while (nt < 7) {
+        while (q < le && ws(*q)) q++;
+        if (q >= le) break;
+        tb[nt] = q;
+        while (q < le && !ws(*q)) q++;
+        te[nt] = q;
+        nt++;
+      }
+      auto digits = [&](int t, bool* ok) {
+        long long v = 0;
+        int nd = 0;
+        for (const char* c = tb[t]; c < te[t]; c++)
+          if (*c >= '0' && *c <= '9') { v = v * 10 + (*c - '0'); nd++; }
+        if (nd == 0 || nd > 9) *ok = false;
+        return (int)v;
+      };
+      if (lb[0] == 'S') {
         bool ok = true;
-        int id = digits_of(name, &ok);
-        if (!ok || tag != "S" || seq.empty()) return AHSOKA_E_PARSE;
+        if (nt < 3 || te[0] - tb[0] != 1) return AHSOKA_E_PARSE;  // tag must be "S", a sequence must follow
+        const int id = digits(1, &ok);
+        if (!ok) return AHSOKA_E_PARSE;
         GNode nd;
         nd.id = id;
         nodes[id] = nd;
-      } else if (line[0] == 'L') {
-        std::stringstream ss(line);
-        std::string tag, a, ao, b, bo;
-        int ov = -1;
-        char unit = 0;
-        ss >> tag >> a >> ao >> b >> bo >> ov >> unit;
+      } else {
         bool ok = true;
-        int ida = digits_of(a, &ok), idb = digits_of(b, &ok);
-        if (!ok || tag != "L" || (ao != "+" && ao != "-") || (bo != "+" && bo != "-") || ov < 0) return AHSOKA_E_PARSE;
+        if (nt < 6 || te[0] - tb[0] != 1) return AHSOKA_E_PARSE;
+        const int ida = digits(1, &ok), idb = digits(3, &ok);
+        const bool a1 = te[2] - tb[2] == 1 && (tb[2][0] == '+' || tb[2][0] == '-');
+        const bool b1 = te[4] - tb[4] == 1 && (tb[4][0] == '+' || tb[4][0] == '-');
+        if (!ok || !a1 || !b1) return AHSOKA_E_PARSE;
+        // overlap "<int><unit>": the unit may also be the next token
+        const char* c = tb[5];
+        long long ov = 0;
+        int nd = 0;
+        bool neg = false;
+        if (c < te[5] && (*c == '+' || *c == '-')) { neg = *c == '-'; c++; }
+        while (c < te[5] && *c >= '0' && *c <= '9') { ov = ov * 10 + (*c - '0'); nd++; c++; }
+        char unit = 0;
+        if (c < te[5]) unit = *c;
+        else if (nt >= 7) unit = tb[6][0];
+        if (nd == 0 || neg || nd > 9) return AHSOKA_E_PARSE;
         if (!(unit == 'M' || (unit == 'S' && ov == 0))) return AHSOKA_E_PARSE;
-        Oriented from{ida, ao == "+"}, to{idb, bo == "+"};
+        Oriented from{ida, tb[2][0] == '+'}, to{idb, tb[4][0] == '+'};
         edges[from].push_back(to);
         // source node first, then the target: both lookups may create a default
         // node (id 0) when an L line precedes its S line (quirk Q15)
@@ -131,29 +176,32 @@ struct Graph {
   // One superbubble walk starting at `start` (a snapshot of the node) along
   // `dir` (false: follow out_plus, true: follow out_minus); appends every bubble
   // found to `chain` and continues from each bubble's sink.
-  void walk(const GNode start, bool dir, GChain* chain) {
+  void walk(const GNode* start, bool dir, GChain* chain) {
+    const int start_id = start->id;
     std::unordered_set<Oriented, OrientedHash> seen;
     std::unordered_set<int> done;
-    std::vector<GNode> inside;
-    seen.insert(Oriented{start.id, dir});
-    // frontier ordered by (node id, direction): the reference keeps a std::set of (Node,bool)
-    std::map<std::pair<int, bool>, GNode> frontier;
-    frontier.emplace(std::make_pair(start.id, dir), start);
+    std::vector<int> inside;
+    seen.insert(Oriented{start_id, dir});
+    // frontier ordered by (node id, direction): the reference keeps a std::set of (Node,bool);
+    // node records are referenced, not copied -- their link lists never change after parsing
+    std::map<std::pair<int, bool>, const GNode*> frontier;
+    frontier.emplace(std::make_pair(start_id, dir), start);
     while (!frontier.empty()) {
       auto first = frontier.begin();
-      const GNode v = first->second;
+      const GNode* v = first->second;
       const bool vdir = first->first.second;
       frontier.erase(first);
-      done.insert(v.id);
-      nodes[v.id].visited = true;
-      inside.push_back(v);
-      seen.erase(Oriented{v.id, vdir});
-      const std::vector<Link>& next = vdir ? v.out_minus : v.out_plus;
+      done.insert(v->id);
+      nodes[v->id].visited = true;
+      inside.push_back(v->id);
+      seen.erase(Oriented{v->id, vdir});
+      const std::vector<Link>& next = vdir ? v->out_minus : v->out_plus;
       if (next.empty()) break;  // tip
       for (const Link& u : next) {
         const bool udir = (u.plus == 0);
-        const std::vector<Link> parents = udir ? nodes[u.to].out_plus : nodes[u.to].out_minus;
-        if (u.to == start.id) {  // walked back into the start: a loop, give up
+        const GNode& un = nodes[u.to];
+        const std::vector<Link>& parents = udir ? un.out_plus : un.out_minus;
+        if (u.to == start_id) {  // walked back into the start: a loop, give up
           frontier.clear();
           break;
         }
@@ -161,25 +209,25 @@ struct Graph {
         bool ready = true;
         for (const Link& p : parents)
           if (!done.count(p.to)) ready = false;
-        if (ready) frontier.emplace(std::make_pair(nodes[u.to].id, udir), nodes[u.to]);
+        if (ready) frontier.emplace(std::make_pair(un.id, udir), &un);
       }
       if (frontier.size() == 1 && seen.size() == 1) {
         auto tit = frontier.begin();
-        const GNode t = tit->second;
+        const GNode* t = tit->second;
         const bool tdir = tit->first.second;
         frontier.erase(tit);
-        inside.push_back(t);
+        inside.push_back(t->id);
         if (inside.size() == 2) break;
         auto drop = [&](int nid) {
           for (size_t i = 0; i < inside.size(); i++)
-            if (inside[i].id == nid) { inside.erase(inside.begin() + (long)i); break; }
+            if (inside[i] == nid) { inside.erase(inside.begin() + (long)i); break; }
         };
-        drop(start.id);
-        drop(t.id);
+        drop(start_id);
+        drop(t->id);
         GBubble b;
-        b.source = start.id;
-        b.sink = t.id;
-        for (const GNode& x : inside) b.inner.push_back(x.id);
+        b.source = start_id;
+        b.sink = t->id;
+        b.inner = inside;
         chain->bubbles.push_back(b);
         walk(t, tdir, chain);
       }
@@ -187,12 +235,12 @@ struct Graph {
   }
 
   void find_chains() {
-    for (auto entry : nodes) {  // by value: the visited flag is the one at this moment
-      GChain ch;
+    for (auto& entry : nodes) {  // the visited flag is read at this moment, as the reference's copy does
       if (!entry.second.visited) {
-        walk(entry.second, false, &ch);
-        walk(entry.second, true, &ch);
-        if (!ch.bubbles.empty()) chains.push_back(ch);
+        GChain ch;
+        walk(&entry.second, false, &ch);
+        walk(&entry.second, true, &ch);
+        if (!ch.bubbles.empty()) chains.push_back(std::move(ch));
       }
     }
     int cid = 0;
@@ -277,13 +325,14 @@ struct GafTable {
 
 inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
 
-// std::stoi / std::stof accept a prefix and throw when nothing converts
+// std::stoi accepts optional white space, a sign and a digit prefix, and throws
+// when nothing converts or the value does not fit an int
 inline bool parses_as_int(const char* b, const char* e) {
-  std::string t(b, e);
-  char* end = nullptr;
-  errno = 0;
-  long v = std::strtol(t.c_str(), &end, 10);
-  return end != t.c_str() && errno != ERANGE && v >= INT32_MIN && v <= INT32_MAX;
+  if (b < e && (*b == '+' || *b == '-')) b++;
+  long long v = 0;
+  int nd = 0;
+  while (b < e && *b >= '0' && *b <= '9' && nd < 12) { v = v * 10 + (*b - '0'); nd++; b++; }
+  return nd > 0 && nd < 12 && v <= 2147483648ll;
 }
 
 struct GafChunk {
@@ -297,6 +346,9 @@ struct GafChunk {
 
 void parse_gaf_chunk(const std::string& buf, size_t beg, size_t end, GafChunk* out) {
   const char* base = buf.data();
+  const size_t guess = (end - beg) / 150 + 16;  // a GAF line is rarely shorter
+  out->name_off.reserve(guess); out->name_len.reserve(guess); out->identity.reserve(guess);
+  out->node_cnt.reserve(guess); out->nodes.reserve(guess * 16);
   size_t pos = beg;
   while (pos < end) {
     const char* nl = (const char*)std::memchr(base + pos, '\n', end - pos);
@@ -324,11 +376,15 @@ void parse_gaf_chunk(const std::string& buf, size_t beg, size_t end, GafChunk* o
     const char* cl = te[15];
     while (cl > tb[15] && cl[-1] != ':') cl--;
     {
-      std::string t(cl, te[15]);
+      // std::stof == strtof on the token (needs a terminator: copy to the stack)
+      char tmp[64];
+      const size_t len = std::min<size_t>((size_t)(te[15] - cl), sizeof(tmp) - 1);
+      std::memcpy(tmp, cl, len);
+      tmp[len] = 0;
       char* endp = nullptr;
       errno = 0;
-      const float v = std::strtof(t.c_str(), &endp);
-      if (endp == t.c_str() || errno == ERANGE) { out->err = AHSOKA_E_PARSE; return; }
+      const float v = std::strtof(tmp, &endp);
+      if (endp == tmp || errno == ERANGE) { out->err = AHSOKA_E_PARSE; return; }
       out->identity.push_back(v);
     }
     if (!parses_as_int(tb[7], te[7]) || !parses_as_int(tb[8], te[8])) { out->err = AHSOKA_E_PARSE; return; }
@@ -365,6 +421,15 @@ int read_gaf(const char* path, GafTable* out) {
     out->buf.resize((size_t)std::max<std::streamoff>(sz, 0));
     if (sz > 0) f.read(&out->buf[0], sz);
   }
+  const bool timing = std::getenv("AHSOKA_INGEST_TIMING") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "  read_gaf %-10s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  };
+  lap("file");
   const std::string& buf = out->buf;
   unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   if (buf.size() < (1u << 20)) nthr = 1;
@@ -380,6 +445,7 @@ int read_gaf(const char* path, GafTable* out) {
   std::vector<std::thread> th;
   for (unsigned t = 0; t < nthr; t++) th.emplace_back(parse_gaf_chunk, std::cref(buf), cut[t], cut[t + 1], &chunks[t]);
   for (auto& x : th) x.join();
+  lap("parse");
   for (auto& c : chunks)
     if (c.err) return c.err;  // the reference aborts at the first malformed line
   size_t nl = 0, nn = 0;
@@ -393,6 +459,7 @@ int read_gaf(const char* path, GafTable* out) {
     for (uint32_t k : c.node_cnt) out->node_off.push_back(out->node_off.back() + k);
     out->nodes.insert(out->nodes.end(), c.nodes.begin(), c.nodes.end());
   }
+  lap("merge");
   return AHSOKA_OK;
 }
 
@@ -472,13 +539,24 @@ extern "C" int ahsoka_ingest_dump(const char* gfa_path, const char* gaf_path, co
 
 extern "C" int ahsoka_ingest(const char* gfa_path, const char* gaf_path, ahsoka_chain_batch** out) {
   if (!gfa_path || !out) return AHSOKA_E_ARG;
+  const bool timing = std::getenv("AHSOKA_INGEST_TIMING") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "ingest %-14s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  };
   try {
     Graph g;
     if (int e = g.read_gfa(gfa_path)) return e;
+    lap("read_gfa");
     g.find_chains();
+    lap("find_chains");
     GafTable gaf;
     if (gaf_path && *gaf_path)
       if (int e = read_gaf(gaf_path, &gaf)) return e;
+    lap("read_gaf");
 
     // size_sorting, src/polyassembly.cpp:136-140: (bubbles, chain id) descending
     std::vector<std::pair<int, int>> order;
@@ -564,6 +642,7 @@ extern "C" int ahsoka_ingest(const char* gfa_path, const char* gaf_path, ahsoka_
       stamp++;
     }
     hb->finish();
+    lap("assemble");
     *out = &hb->view;
   } catch (const std::bad_alloc&) {
     return AHSOKA_E_NOMEM;
