@@ -272,3 +272,30 @@ def test_cli_end_to_end(tmp_path):
     # per-chain files hold the node lines only (src/alignmentstoreadset.cpp:411-412,449,456)
     lines = open(prefix + "-chain9-result.txt").read().split("\n")
     assert len(lines) == 3 and lines[0].endswith("),") and lines[2] == ""
+
+
+def test_degenerate_batches():
+    """empty batch, a chain without bubbles, a chain without reads, a single chain"""
+    from random_batches import random_batch
+    empty = capi.ChainBatch(arrays={k: np.zeros(0 if not k.endswith("_off") else 1, dtype=np.int64 if k.endswith("_off") else np.int32)
+                                    for k in ("chain_id", "bubble_off", "allele_off", "apath_off", "apath_node", "node_off", "node_id",
+                                              "read_off", "rnode_off", "rnode", "read_mapq", "read_name")})
+    g = capi.phase_batch(empty)
+    assert g.n_chains == 0
+    for seed in (5000, 5001):
+        b = random_batch(seed, n_chains=1, max_bubbles=0, max_reads=3)
+        _compare(b, capi.default_params(want_stages=1))
+    b = capi.synth_batch(n_chains=1, n_bubbles=9, n_reads=70, seed=77)
+    _compare(b, capi.default_params(want_stages=1))
+
+
+@pytest.mark.parametrize("ploidy", [3, 4])
+def test_other_ploidies(ploidy):
+    """ploidy is a parameter of the ABI (reference literal 2, quirk Q17); tuples = (2p)^p"""
+    b = capi.synth_batch(n_chains=4, n_bubbles=10, n_reads=150, ploidy=ploidy, seed=900 + ploidy)
+    _compare(b, capi.default_params(want_stages=1, ploidy=ploidy))
+    # reference literal genotype {0:1,1:1} with ploidy > 2: nothing conforms, all tuples are used
+    a = b.arrays()
+    a.pop("genotype")
+    nb = capi.ChainBatch(arrays={k: v for k, v in a.items() if v is not None})
+    _compare(nb, capi.default_params(want_stages=1, ploidy=ploidy))
