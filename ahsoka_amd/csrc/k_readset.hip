@@ -8,7 +8,8 @@
 //   S2b  filter                    :262-282
 //   S3   ReadSet::sort()           :296-297
 //
-// is_subset (:495-548) on de-duplicated allele paths is a bit test: every
+// is_subset (:495-548) on allele paths without repeated nodes is a bit test
+// (paths that repeat a node take the exact multiset-counting path): every
 // alignment's node list becomes a bitset over the chain's nodes, held in LDS
 // (one u64 column per lane, so a wave-uniform node index hits 64 different
 // banks), and an allele matches when all of its path nodes (S1) or all inner
@@ -53,6 +54,24 @@ __device__ __forceinline__ int merged_allele(const signed char* __restrict__ v, 
   }
   *creator = best_r;
   return best_r >= 0 ? best_a : -1;
+}
+
+// std::includes on sorted ranges is a MULTISET test (quirk Q5): for an allele
+// path that repeats a node the bit test is not enough, the alignment must visit
+// that node at least as often.  Rare (cyclic bubbles): exact counting loop.
+__device__ bool multiset_includes(const int* __restrict__ path, long long pb, long long pe, const int* __restrict__ rn,
+                                  long long rb, long long re) {
+  for (long long e = pb; e < pe; e++) {
+    const int nd = path[e];
+    bool seen_before = false;
+    for (long long e2 = pb; e2 < e; e2++) seen_before = seen_before || path[e2] == nd;
+    if (seen_before) continue;
+    int cp = 0, cr = 0;
+    for (long long e2 = e; e2 < pe; e2++) cp += path[e2] == nd;
+    for (long long q = rb; q < re; q++) cr += rn[q] == nd;
+    if (cr < cp) return false;
+  }
+  return true;
 }
 
 __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds lds) {
@@ -107,6 +126,13 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
       const long long a0 = aoff[k], a1 = aoff[k + 1];
       for (long long a = a0; a < a1 && (vf < 0 || vp < 0); a++) {
         const long long p0 = db.apath_off[a], p1 = db.apath_off[a + 1];
+        if (db.apath_dup[a]) {  // path repeats a node: exact multiset containment
+          const bool inner_d = p1 - p0 >= 2 ? multiset_includes(db.apath_node, p0 + 1, p1 - 1, db.rnode, e0, e1) : true;
+          const bool full_d = multiset_includes(db.apath_node, p0, p1, db.rnode, e0, e1);
+          if (vp < 0 && inner_d) vp = (int)(a - a0);
+          if (vf < 0 && full_d) vf = (int)(a - a0);
+          continue;
+        }
         bool inner = true;
         for (long long e = p0 + 1; e < p1 - 1; e++) {
           int nd = db.apath_node[e];

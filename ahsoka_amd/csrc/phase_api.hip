@@ -184,6 +184,7 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   h->meta.resize(C);
   std::vector<long long> name_off;
   std::vector<int> name_aln((size_t)in->read_off[C]);
+  std::vector<unsigned char> apath_dup((size_t)in->allele_off[in->bubble_off[C]] + 1, 0);
   int maxA = 2, maxG = 1, maxB = 1, maxN = 1;
   long long vm = 0, fr = 0, cov = 0, dump = 0;
   for (int c = 0; c < C; c++) {
@@ -215,12 +216,12 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
       if (na > kMaxAlleles) unsupported = true;
       maxA = std::max(maxA, std::min(na, kMaxAlleles));
       for (long long a = in->allele_off[g]; a < in->allele_off[g + 1]; a++) {
-        // std::includes is a multiset test (quirk Q5); the bit test equals it
-        // only for paths without repeated nodes
+        // std::includes is a multiset test (quirk Q5); the bit test equals it only
+        // for paths without repeated nodes: flag the others for the counting path
         const long long p0 = in->apath_off[a], p1 = in->apath_off[a + 1];
-        for (long long e = p0; e < p1 && !unsupported; e++)
+        for (long long e = p0; e < p1 && !apath_dup[(size_t)a]; e++)
           for (long long e2 = e + 1; e2 < p1; e2++)
-            if (in->apath_node[e] == in->apath_node[e2]) { unsupported = true; break; }
+            if (in->apath_node[e] == in->apath_node[e2]) { apath_dup[(size_t)a] = 1; break; }
       }
     }
     m.flags = unsupported ? 1 : 0;
@@ -258,6 +259,7 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   if ((rc = h->dupload(&db.allele_off, (const long long*)in->allele_off, (size_t)SB + 1))) return fail(rc);
   if ((rc = h->dupload(&db.apath_off, (const long long*)in->apath_off, (size_t)SA + 1))) return fail(rc);
   if ((rc = h->dupload(&db.apath_node, (const int*)in->apath_node, (size_t)SP))) return fail(rc);
+  if ((rc = h->dupload(&db.apath_dup, (const unsigned char*)apath_dup.data(), (size_t)SA + 1))) return fail(rc);
   if (in->genotype) {
     if ((rc = h->dupload(&db.genotype, (const int*)in->genotype, (size_t)SA))) return fail(rc);
   } else {

@@ -43,6 +43,7 @@ struct DeviceBatch {
   const long long* allele_off;
   const long long* apath_off;
   const int* apath_node;
+  const unsigned char* apath_dup;  // [SA] 1 if the allele path repeats a node (multiset containment needed)
   const int* genotype;  // may be null
   const long long* rnode_off;
   const int* rnode;

@@ -7,7 +7,7 @@ import numpy as np
 from ahsoka_amd import capi
 
 
-def random_batch(seed, n_chains=4, max_bubbles=14, max_reads=120, max_alleles=5):
+def random_batch(seed, n_chains=4, max_bubbles=14, max_reads=120, max_alleles=5, dup_paths=False):
     rng = np.random.default_rng(seed)
     A = {k: [] for k in ("chain_id", "apath_node", "node_id", "rnode", "read_mapq", "read_name")}
     off = {k: [0] for k in ("bubble_off", "allele_off", "apath_off", "node_off", "read_off", "rnode_off")}
@@ -27,6 +27,8 @@ def random_batch(seed, n_chains=4, max_bubbles=14, max_reads=120, max_alleles=5)
                 inner = list(range(n_local, n_local + ninner))
                 n_local += ninner
                 p = [k] + inner + [k + 1]
+                if dup_paths and inner and rng.random() < 0.3:
+                    p = [k] + inner + [inner[0]] + [k + 1]  # the path visits a node twice (multiset containment)
                 if rng.random() < 0.3:
                     p = p[::-1]  # sink -> source, like the reference's DFS paths (quirk Q7)
                 paths.append(p)
@@ -57,6 +59,8 @@ def random_batch(seed, n_chains=4, max_bubbles=14, max_reads=120, max_alleles=5)
                     p = p if p[0] == k else p[::-1]
                     if rng.random() < 0.1:
                         p = [p[0], p[-1]]  # the read jumps over the inner nodes
+                    if dup_paths and rng.random() < 0.3 and len(p) > 3:
+                        p = [q for q in p if q != p[1]] + [p[1]] if rng.random() < 0.5 else p  # sometimes only one visit
                     path.extend(p if not path else p[1:])
                 if rng.random() < 0.1:
                     path.insert(int(rng.integers(0, len(path) + 1)), -1)  # node of another chain

@@ -299,3 +299,14 @@ def test_other_ploidies(ploidy):
     a.pop("genotype")
     nb = capi.ChainBatch(arrays={k: v for k, v in a.items() if v is not None})
     _compare(nb, capi.default_params(want_stages=1, ploidy=ploidy))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_allele_paths_with_repeated_nodes(seed):
+    """std::includes is a multiset test (quirk Q5): paths that visit a node twice need
+    the alignment to visit it twice"""
+    from random_batches import random_batch
+
+    b = random_batch(7000 + seed, dup_paths=True)
+    g, o = _compare(b, capi.default_params(want_stages=1, min_mapq=90))
+    assert (g.status != capi.ST_UNSUPPORTED).all()
