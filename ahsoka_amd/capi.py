@@ -106,7 +106,7 @@ class CSynthSpec(C.Structure):
 ABI_SYMBOLS = [
     "ahsoka_default_params", "ahsoka_backend_info", "ahsoka_abi_version", "ahsoka_phase_batch",
     "ahsoka_result_free", "ahsoka_batch_upload", "ahsoka_phase_device", "ahsoka_batch_download",
-    "ahsoka_batch_free", "ahsoka_batch_kernel_times", "ahsoka_batch_bytes", "ahsoka_render_chain",
+    "ahsoka_batch_free", "ahsoka_batch_result_device", "ahsoka_batch_kernel_times", "ahsoka_batch_bytes", "ahsoka_render_chain",
     "ahsoka_ingest", "ahsoka_ingest_dump", "ahsoka_batch_host_free", "ahsoka_synth_batch", "ahsoka_synth_write_text", "ahsoka_synth_truth",
     "ahsoka_test_introsort_u32", "ahsoka_test_detlog",
 ]
@@ -136,6 +136,7 @@ def lib() -> C.CDLL:
     L.ahsoka_batch_download.argtypes = [C.c_void_p, C.POINTER(CPhaseResult)]
     L.ahsoka_batch_free.argtypes = [C.c_void_p]
     L.ahsoka_batch_free.restype = None
+    L.ahsoka_batch_result_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.ahsoka_batch_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_char_p)),
                                             C.POINTER(C.POINTER(C.c_float))]
     L.ahsoka_batch_bytes.argtypes = [C.POINTER(CChainBatch), C.c_int32, C.POINTER(C.c_int64)]
@@ -414,6 +415,28 @@ class DeviceBatch:
         ms = C.POINTER(C.c_float)()
         _check(lib().ahsoka_batch_kernel_times(self._h, C.byref(n), C.byref(names), C.byref(ms)), "kernel_times")
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+    def result_device(self):
+        """(device pointer, number of int32) of the packed result record block
+        [status | npos | pos | hap_allele]; owned by this handle."""
+        ptr = C.c_void_p()
+        n = C.c_int64()
+        _check(lib().ahsoka_batch_result_device(self._h, C.byref(ptr), C.byref(n)), "ahsoka_batch_result_device")
+        return int(ptr.value), int(n.value)
+
+    def result_tensor(self):
+        """The packed result block as a torch int32 CUDA tensor (a view of library
+        memory: valid until the next phase() / free())."""
+        import torch
+
+        ptr, n = self.result_device()
+
+        class _Ext:  # __cuda_array_interface__ carrier
+            pass
+
+        e = _Ext()
+        e.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+        return torch.as_tensor(e, device=torch.device("cuda", self.params.device))
 
     def download(self) -> PhaseResult:
         r = CPhaseResult()

@@ -57,6 +57,7 @@ struct ahsoka_device_batch {
   int maxG = 1, maxB = 1, n_cu = 1;
   size_t lds_per_block = 0;
   bool ws_ready = false;
+  int* packed = nullptr;  // [status | npos | pos | hap_allele] for ahsoka_batch_result_device
   int slots = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -413,6 +414,23 @@ extern "C" int ahsoka_phase_device(ahsoka_device_batch* h) {
   HIP_TRY(hipEventElapsedTime(&h->k_ms[0], h->ev[0], h->ev[1]));
   HIP_TRY(hipEventElapsedTime(&h->k_ms[1], h->ev[1], h->ev[2]));
   h->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return AHSOKA_OK;
+}
+
+extern "C" int ahsoka_batch_result_device(ahsoka_device_batch* h, void** dev_ptr, int64_t* n_int32) {
+  if (!h || !dev_ptr || !n_int32) return AHSOKA_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t C = (size_t)h->C, SB = (size_t)h->sumB, p = (size_t)h->prm.ploidy;
+  const size_t total = 2 * C + SB + p * SB;
+  if (!h->packed)
+    if (int rc = h->dalloc(&h->packed, total)) return rc;
+  HIP_TRY(hipMemcpyAsync(h->packed, h->db.status, C * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->packed + C, h->db.npos, C * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->packed + 2 * C, h->db.pos, SB * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->packed + 2 * C + SB, h->db.hap_allele, p * SB * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *dev_ptr = h->packed;
+  *n_int32 = (int64_t)total;
   return AHSOKA_OK;
 }
 

@@ -99,11 +99,12 @@ def unpack_records(rec: np.ndarray, ploidy: int, max_pos: int):
 
 
 def gather_to_rank0(res: PhaseResult, owned: np.ndarray, n_total: int, max_pos: int, device=None, group=None,
-                    max_chains: Optional[int] = None):
+                    max_chains: Optional[int] = None, unpack: bool = True):
     """The single collective of the path.  ``owned`` = global chain indices of this
     rank's shard, in the order the shard was phased.  Returns on rank 0
     (status, pos_off, pos, hap_allele) for all n_total chains in global chain
-    order, on other ranks None.  ``max_chains`` = largest shard (records are
+    order (``unpack=False``: the fixed-width GatheredRecords instead, which is all
+    the hot loop needs), on other ranks None.  ``max_chains`` = largest shard (records are
     padded to it); a block partition knows it without communication, otherwise
     it is agreed on with one extra tiny all_gather."""
     import torch
@@ -126,7 +127,73 @@ def gather_to_rank0(res: PhaseResult, owned: np.ndarray, n_total: int, max_pos: 
         return None
     allrec = torch.cat(bufs, dim=0).cpu().numpy()
     allrec = allrec[allrec[:, 0] >= 0]
-    order = np.argsort(allrec[:, 0], kind="stable")
-    allrec = allrec[order]
+    if not (np.diff(allrec[:, 0]) > 0).all():  # block partitions arrive in global order already
+        allrec = allrec[np.argsort(allrec[:, 0], kind="stable")]
     assert len(allrec) == n_total and (allrec[:, 0] == np.arange(n_total)).all(), "shards do not tile the chain list"
-    return unpack_records(allrec[:, 1:], res.ploidy, max_pos)
+    rec = GatheredRecords(allrec[:, 1:], res.ploidy, max_pos)
+    return rec.unpack() if unpack else rec
+
+
+class GatheredRecords:
+    """All chains' result records on rank 0, in global chain order: one fixed-width
+    int32 row per chain [status, P, pos[max_pos], hap[ploidy][max_pos]] (padding -1).
+    ``unpack()`` gives the ragged (status, pos_off, pos, hap_allele) arrays of a
+    PhaseResult; rendering and tests use it, the hot loop does not need to."""
+
+    def __init__(self, rec: np.ndarray, ploidy: int, max_pos: int):
+        self.rec, self.ploidy, self.max_pos = rec, ploidy, max_pos
+
+    @property
+    def status(self) -> np.ndarray:
+        return self.rec[:, 0]
+
+    def chain_haps(self, c: int) -> np.ndarray:
+        P = int(self.rec[c, 1])
+        o = 2 + self.max_pos
+        return np.stack([self.rec[c, o + i * self.max_pos: o + i * self.max_pos + P] for i in range(self.ploidy)])
+
+    def chain_pos(self, c: int) -> np.ndarray:
+        return self.rec[c, 2:2 + int(self.rec[c, 1])]
+
+    def unpack(self):
+        return unpack_records(self.rec, self.ploidy, self.max_pos)
+
+
+def gather_device_blocks(block, group=None):
+    """The single collective of the path on device memory: every rank passes its
+    packed result block (DeviceBatch.result_tensor(): [status | npos | pos | hap],
+    same length on every rank for equal shard shapes); rank 0 gets the list of all
+    ranks' blocks (still on its GPU), other ranks None.  With backend "nccl" this is
+    one RCCL gather over xGMI and no host staging."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    bufs = [torch.empty_like(block) for _ in range(world)] if rank == 0 else None
+    dist.gather(block, bufs, dst=0, group=group)
+    return bufs
+
+
+def decode_block(block: np.ndarray, bubble_off: np.ndarray, ploidy: int):
+    """host view of one packed block -> (status, pos_off, pos, hap_allele) like PhaseResult"""
+    C = len(bubble_off) - 1
+    SB = int(bubble_off[-1])
+    status = block[:C].astype(np.int32)
+    npos = np.where(status == 0, block[C:2 * C], 0).astype(np.int64)
+    pos_raw = block[2 * C:2 * C + SB]
+    hap_raw = block[2 * C + SB:]
+    pos_off = np.concatenate([[0], np.cumsum(npos)]).astype(np.int64)
+    total = int(pos_off[-1])
+    if total == 0:
+        return status, pos_off, np.zeros(0, np.int32), np.zeros(0, np.int32)
+    row = np.repeat(np.arange(C), npos)
+    col = np.arange(total) - np.repeat(pos_off[:-1], npos)
+    pos = pos_raw[bubble_off[:-1][row] + col].astype(np.int32)
+    hap = np.empty(ploidy * total, dtype=np.int32)
+    base_out = ploidy * np.repeat(pos_off[:-1], npos)
+    base_in = ploidy * bubble_off[:-1][row]
+    Prep = np.repeat(npos, npos)
+    for i in range(ploidy):
+        hap[base_out + i * Prep + col] = hap_raw[base_in + i * Prep + col]
+    return status, pos_off, pos, hap

@@ -93,7 +93,10 @@ def main():
         res = dev.download()
         gathered = None
         if world > 1:
-            gathered = shard.gather_to_rank0(res, owned, per_gpu * world, max_pos, device=coll_device, max_chains=per_gpu)
+            # the one collective of the path: every rank's packed result block
+            # (device memory, fixed layout) to rank 0 -- RCCL gather over xGMI
+            block = dev.result_tensor()
+            gathered = shard.gather_device_blocks(block if backend == "nccl" else block.cpu())
         return res, gathered
 
     def fence():

@@ -175,6 +175,15 @@ void ahsoka_batch_free(ahsoka_device_batch* handle);
  * the launch stream); names/ms arrays are owned by the handle. */
 int ahsoka_batch_kernel_times(ahsoka_device_batch* handle, int32_t* n, const char*** names,
                               const float** ms);
+/*
+ * The result of the last ahsoka_phase_device call as ONE device-resident int32
+ * record block with a layout that depends only on the batch shape, so that ranks
+ * can exchange results with a single fixed-size collective (RCCL gather) without
+ * touching the host:   [ status[C] | npos[C] | pos[SB] | hap_allele[ploidy*SB] ]
+ * chain c: pos at bubble_off[c] (npos[c] valid entries), haplotype i of chain c at
+ * C+C+SB + ploidy*bubble_off[c] + i*npos[c].  *dev_ptr stays owned by the handle.
+ */
+int ahsoka_batch_result_device(ahsoka_device_batch* handle, void** dev_ptr, int64_t* n_int32);
 /* bytes of the batch as laid out in HBM, and algorithmic bytes */
 int ahsoka_batch_bytes(const ahsoka_chain_batch* in, int32_t ploidy, int64_t* algorithmic_bytes);
 

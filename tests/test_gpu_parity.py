@@ -310,3 +310,20 @@ def test_allele_paths_with_repeated_nodes(seed):
     b = random_batch(7000 + seed, dup_paths=True)
     g, o = _compare(b, capi.default_params(want_stages=1, min_mapq=90))
     assert (g.status != capi.ST_UNSUPPORTED).all()
+
+
+def test_device_result_block_matches_download():
+    """the packed device-resident result block (what ranks gather over RCCL) decodes
+    to exactly what ahsoka_batch_download returns"""
+    from ahsoka_amd import shard
+    b = capi.synth_batch(n_chains=40, n_bubbles=17, n_reads=120, seed=314)
+    dev = capi.DeviceBatch(b, capi.default_params())
+    dev.phase()
+    res = dev.download()
+    blk = dev.result_tensor().cpu().numpy()
+    status, pos_off, pos, hap = shard.decode_block(blk, b.arrays()["bubble_off"], 2)
+    dev.free()
+    np.testing.assert_array_equal(status, res.status)
+    np.testing.assert_array_equal(pos_off, res.pos_off)
+    np.testing.assert_array_equal(pos, res.pos)
+    np.testing.assert_array_equal(hap, res.hap_allele)
