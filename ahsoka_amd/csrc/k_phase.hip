@@ -39,6 +39,7 @@
     if (tid == 0) {                                      \
       const long long _t = (long long)clock64();         \
       tacc[slot] += _t - tlast;                          \
+      if (heavy_it) tacc2[slot] += _t - tlast;           \
       tlast = _t;                                        \
     }                                                    \
   } while (0)
@@ -132,29 +133,82 @@ __device__ __forceinline__ int new_w(int r1, int r2, bool merge) {
 // reads column accesses: one HBM line per 16 useful bytes.)
 __device__ __forceinline__ unsigned ic_index(int r, int c, int n) { return (unsigned)(r * n + c); }
 
-// Exact maximum of row r over its live edges: scalar loop over the non-empty
-// bitmap words, lane = bit; the loads of successive words do not depend on each
-// other and stay in flight together (measured faster than expanding the columns
-// into LDS first).
-__device__ __forceinline__ void rescan_row(int r, int n, int nw, int lane, const unsigned long long* __restrict__ LV,
-                                           const IcPair* __restrict__ IC, unsigned long long* kF_out, unsigned long long* kP_out) {
-  const unsigned long long bmw = lane < nw ? LV[(unsigned)(r * nw + lane)] : 0ull;
-  unsigned long long todo = __ballot(bmw != 0ull);
-  unsigned long long kF = 0, kP = 0;
-  while (todo != 0ull) {
-    const int l = __builtin_ctzll(todo);
-    todo &= todo - 1ull;
-    const unsigned long long w = readlane_u64(bmw, l);
-    if ((w >> lane) & 1ull) {
-      const int b = (l << 6) + lane;
-      const IcPair v = IC[ic_index(r, b, n)];
-      const unsigned long long k1 = mkkey(v.f, b), k2 = mkkey(v.p, b);
-      kF = k1 > kF ? k1 : kF;
-      kP = k2 > kP ? k2 : kP;
+// Exact maxima of rows r0 and r1 (r1 < 0: none) over their live edges.  Lane = bit
+// of a 64-column bitmap word; the non-empty words of both rows form one work list
+// that is consumed four words at a time: the four induced-cost loads of a batch are
+// issued before any of them is used (a load-use pair per loop trip would cost one
+// HBM round trip per word, and a row's live edges sit in 2-4 words).
+__device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int lane, const unsigned long long* __restrict__ LV,
+                                             const IcPair* __restrict__ IC, unsigned long long* keys /* F0 P0 F1 P1 */) {
+  const unsigned long long bm0 = lane < nw ? LV[(unsigned)(r0 * nw + lane)] : 0ull;
+  const unsigned long long bm1 = (r1 >= 0 && lane < nw) ? LV[(unsigned)(r1 * nw + lane)] : 0ull;
+  unsigned long long todo0 = __ballot(bm0 != 0ull), todo1 = __ballot(bm1 != 0ull);
+  unsigned long long kF0 = 0, kP0 = 0, kF1 = 0, kP1 = 0;
+  while ((todo0 | todo1) != 0ull) {
+    IcPair v[4];
+    int col[4];
+    bool second[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      col[c] = -1;
+      second[c] = false;
+      int l = -1;
+      unsigned long long w = 0ull;
+      if (todo0 != 0ull) {
+        l = __builtin_ctzll(todo0);
+        todo0 &= todo0 - 1ull;
+        w = readlane_u64(bm0, l);
+      } else if (todo1 != 0ull) {
+        l = __builtin_ctzll(todo1);
+        todo1 &= todo1 - 1ull;
+        w = readlane_u64(bm1, l);
+        second[c] = true;
+      }
+      if (l >= 0 && ((w >> lane) & 1ull)) {
+        col[c] = (l << 6) + lane;
+        v[c] = IC[ic_index(second[c] ? r1 : r0, col[c], n)];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (col[c] < 0) continue;
+      const unsigned long long k1 = mkkey(v[c].f, col[c]), k2 = mkkey(v[c].p, col[c]);
+      if (second[c]) {
+        kF1 = k1 > kF1 ? k1 : kF1;
+        kP1 = k2 > kP1 ? k2 : kP1;
+      } else {
+        kF0 = k1 > kF0 ? k1 : kF0;
+        kP0 = k2 > kP0 ? k2 : kP0;
+      }
     }
   }
-  *kF_out = wave_max_u64(kF);
-  *kP_out = wave_max_u64(kP);
+  keys[0] = wave_max_u64(kF0);
+  keys[1] = wave_max_u64(kP0);
+  if (r1 >= 0) {
+    keys[2] = wave_max_u64(kF1);
+    keys[3] = wave_max_u64(kP1);
+  }
+}
+
+// rows dlist[0..nd): wave wv takes pairs of rows
+__device__ __forceinline__ void rescan_list(const unsigned short* dlist, int nd, int wv, int lane, int n, int nw,
+                                            const unsigned long long* __restrict__ LV, const IcPair* __restrict__ IC,
+                                            unsigned long long* bestF, unsigned long long* bestP, unsigned int* stalew) {
+  for (int di = 2 * wv; di < nd; di += 8) {
+    const int r0 = dlist[di], r1 = di + 1 < nd ? (int)dlist[di + 1] : -1;
+    unsigned long long keys[4];
+    rescan_rows2(r0, r1, n, nw, lane, LV, IC, keys);
+    if (lane == 0) {
+      bestF[r0] = keys[0];
+      bestP[r0] = keys[1];
+      atomicAnd(&stalew[r0 >> 5], ~(1u << (r0 & 31)));
+      if (r1 >= 0) {
+        bestF[r1] = keys[2];
+        bestP[r1] = keys[3];
+        atomicAnd(&stalew[r1 >> 5], ~(1u << (r1 & 31)));
+      }
+    }
+  }
 }
 
 struct GreaterCnt {  // cmp() of the reference, :699-701: coverage descending
@@ -206,7 +260,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
   unsigned short* rowbuf = listFb + nmax;                 // [4][nmax] per-wave column buffers
   unsigned short* dlist = rowbuf + 4 * (size_t)nmax;      // [nmax] rows whose maximum must be rescanned
   unsigned int* stalew = (unsigned int*)(dlist + nmax);   // [nmax/32] bit per row: already in dlist
-  unsigned long long* rmask = (unsigned long long*)(stalew + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][32] role masks per 64-column word
+  unsigned int* multiw = stalew + ((nmax + 31) / 32 + 1) / 2 * 2;  // [nmax/32] bit per read: its clique has > 1 member
+  unsigned long long* rmask = (unsigned long long*)(multiw + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][32] role masks per 64-column word
   unsigned long long* rolenz = rmask + 4 * 32;             // [4][32] OR of the members' nz-rows
   unsigned char* role = (unsigned char*)(rolenz + 4 * 32);  // [nmax]
   __shared__ int s_chain, s_cnt[4], s_nd, s_items;
@@ -428,7 +483,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         }
       }
     }
-    for (int u = tid; u < (n + 31) / 32; u += kBlock) stalew[u] = 0;
+    for (int u = tid; u < (n + 31) / 32; u += kBlock) { stalew[u] = 0; multiw[u] = 0; }
     if (tid < 4) s_cnt[tid] = 0;
     if (tid == 0) { s_nd = 0; s_items = 0; }
     __syncthreads();
@@ -437,8 +492,14 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     // ================= S5 main loop ========================================
     long long iters = 0;
 #ifdef AHK_TIMING
+    int s_items_last = 0;
     if (tid == 0) s_chg = 0;
     long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)clock64(), nretry = 0, nresc = 0, sumT = 0, sumM = 0, sumW = 0;
+    long long hM[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hMc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hT[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hTc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, titer = tlast, nmerge = 0, sumnd = 0, nfast = 0;
+    long long tacc2[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, nheavy = 0;
+    bool heavy_it = false;
+    long long h2[32], h2c[32], h2m[32];
+    for (int q = 0; q < 32; q++) { h2[q] = 0; h2c[q] = 0; h2m[q] = 0; }
 #endif
     for (;;) {
       // ---- P1: edge with the largest icf and edge with the largest icp ----
@@ -502,17 +563,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         }
         __syncthreads();
         {
-          const int nd = s_nd;
-          for (int di = wv; di < nd; di += 4) {
-            const int r = dlist[di];
-            unsigned long long kF, kP;
-            rescan_row(r, n, nw, lane, LV, IC, &kF, &kP);
-            if (lane == 0) {
-              bestF[r] = kF;
-              bestP[r] = kP;
-              atomicAnd(&stalew[r >> 5], ~(1u << (r & 31)));
-            }
-          }
+          rescan_list(dlist, s_nd, wv, lane, n, nw, LV, IC, bestF, bestP, stalew);
         }
         __syncthreads();
 #ifdef AHK_TIMING
@@ -527,6 +578,103 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       const int eu = merge ? (int)(abf >> 16) : (int)(abp >> 16);
       const int ev = merge ? (int)(abf & 0xffff) : (int)(abp & 0xffff);
       const int cu = cl[eu], cv = cl[ev];
+
+      // ---- fast path: separation of two single reads (9 of 10 iterations) ------
+      // The only rewritten pair is (eu,ev); the only induced costs that can change
+      // are those of the live edges (x,b), x in {eu,ev}, through the one triangle
+      // (x,w,b) with w the other end -- and only where W[w][b] != 0.  Two waves per
+      // row x (lane = column bit of a live word): every live edge of the row is
+      // loaded, the candidates among them updated, and the row's exact new maximum
+      // falls out of the same pass (the general path would queue both rows for a
+      // rescan: their maximum is the edge that dies).  Two dependent HBM round
+      // trips per iteration instead of about ten.
+      if (!merge && !(((multiw[eu >> 5] >> (eu & 31)) | (multiw[ev >> 5] >> (ev & 31))) & 1u)) {
+        const int half = wv >> 1, sub = wv & 1;
+        const int x = half ? ev : eu, w = half ? eu : ev;
+        unsigned long long lvn = 0ull, nzo = 0ull;
+        if (lane < nw) {
+          lvn = LV[(unsigned)(x * nw + lane)];
+          nzo = NZ[(unsigned)(w * nw + lane)];
+        }
+        const int ov = Wm[(unsigned)(eu * n + ev)];  // wave-uniform
+        if (lane == (w >> 6)) {
+          lvn &= ~(1ull << (w & 63));
+          if (sub == 0) LV[(unsigned)(x * nw + lane)] = lvn;
+        }
+        unsigned long long todo = __ballot(lvn != 0ull);
+        unsigned long long kF = 0ull, kP = 0ull;
+        // this wave takes the live words of even (sub 0) / odd (sub 1) rank, two per trip
+        while (todo != 0ull) {
+          int lw[2];
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            if (sub && todo != 0ull) todo &= todo - 1ull;
+            lw[c] = todo != 0ull ? __builtin_ctzll(todo) : -1;
+            if (todo != 0ull) todo &= todo - 1ull;
+            if (!sub && todo != 0ull) todo &= todo - 1ull;
+          }
+          IcPair icv[2];
+          int wb[2];
+          bool on[2];
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            on[c] = false;
+            wb[c] = 0;
+            if (lw[c] >= 0) {
+              const unsigned long long wd = readlane_u64(lvn, lw[c]);
+              const unsigned long long cd = wd & readlane_u64(nzo, lw[c]);
+              if ((wd >> lane) & 1ull) {
+                const int b = (lw[c] << 6) + lane;
+                on[c] = true;
+                icv[c] = IC[ic_index(x, b, n)];
+                if ((cd >> lane) & 1ull) wb[c] = Wm[(unsigned)(w * n + b)];
+              }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            if (!on[c]) continue;
+            const int b = (lw[c] << 6) + lane;
+            IcPair ic = icv[c];
+            const long long df = (long long)icf_term(W_FORB, wb[c]) - (long long)icf_term(ov, wb[c]);
+            const long long dp = (long long)icp_term(W_FORB, wb[c]) - (long long)icp_term(ov, wb[c]);
+            if (df != 0 || dp != 0) {
+              ic.f += df;
+              ic.p += dp;
+              IC[ic_index(x, b, n)] = ic;
+              IC[ic_index(b, x, n)] = ic;
+              const unsigned long long c1 = mkkey(ic.f, x), c2 = mkkey(ic.p, x);
+              const unsigned long long k1 = bestF[b], k2 = bestP[b];
+              if ((k1 && key_col(k1) == x && c1 < k1) || (k2 && key_col(k2) == x && c2 < k2))
+                atomicOr(&stalew[b >> 5], 1u << (b & 31));
+              atomicMax(&bestF[b], c1);
+              atomicMax(&bestP[b], c2);
+            }
+            const unsigned long long r1 = mkkey(ic.f, b), r2 = mkkey(ic.p, b);
+            kF = r1 > kF ? r1 : kF;
+            kP = r2 > kP ? r2 : kP;
+          }
+        }
+        kF = wave_max_u64(kF);
+        kP = wave_max_u64(kP);
+        if (lane == 0) { s_rk[wv] = kF; s_rk[4 + wv] = kP; }
+        __syncthreads();
+        if (tid < 2) {
+          const int xr = tid ? ev : eu;
+          const unsigned long long a1 = s_rk[2 * tid], a2 = s_rk[2 * tid + 1], b1 = s_rk[4 + 2 * tid], b2 = s_rk[4 + 2 * tid + 1];
+          bestF[xr] = a1 > a2 ? a1 : a2;
+          bestP[xr] = b1 > b2 ? b1 : b2;
+          atomicAnd(&stalew[xr >> 5], ~(1u << (xr & 31)));
+          Wm[(unsigned)(xr * n + (tid ? eu : ev))] = W_FORB;  // every wave has read the old weight by now
+        }
+        __syncthreads();
+#ifdef AHK_TIMING
+        AHK_T(11);
+        nfast++;
+        titer = (long long)clock64();
+#endif
+        continue;
+      }
 
       // ---- P2: roles, member lists and per-word role masks --------------------
       // (s_cnt was zeroed before the last barrier).  rmask[R][k] has bit c set iff
@@ -563,6 +711,10 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       __syncthreads();
       const int nA = s_cnt[0], nB = s_cnt[1], nFa = s_cnt[2], nFb = s_cnt[3];
       const int nT = nA + nB + nFa + nFb;
+#ifdef AHK_TIMING
+      heavy_it = (nA + nFa > 64 && nB + nFb <= 1) || (nB + nFb > 64 && nA + nFa <= 1);
+      nheavy += heavy_it ? 1 : 0;
+#endif
       // ---- P2b: per role, the OR of the nz-rows of its members (wave R <-> role R):
       // "some member w of the role has W[w][b] != 0".  One pass per iteration,
       // shared by every row of P3a; lists longer than 32 are not filtered.
@@ -699,6 +851,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         const int M = s_items;
 #ifdef AHK_TIMING
         sumM += M;
+        s_items_last = M;
 #endif
         for (int i = tid; i < M; i += kBlock) {
           const unsigned int it = i < cap ? items_lds[i] : items_glb[i - cap];
@@ -831,24 +984,39 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             Wm[(unsigned)(y * n + x)] = N;
           }
         }
-        if (merge)
-          for (int yi = tid; yi < nB; yi += kBlock) cl[listB[yi]] = (unsigned short)cu;
+        if (merge) {
+          for (int yi = tid; yi < nB; yi += kBlock) {
+            const int y = listB[yi];
+            cl[y] = (unsigned short)cu;
+            atomicOr(&multiw[y >> 5], 1u << (y & 31));
+          }
+          for (int xi = tid; xi < nA; xi += kBlock) {
+            const int x = listA[xi];
+            atomicOr(&multiw[x >> 5], 1u << (x & 31));
+          }
+        }
         if (tid < 4) s_cnt[tid] = 0;
         if (tid == 0) s_items = 0;
         // rows whose maximum died: exact rescan now (they would tie the next argmax anyway)
-        const int nd = s_nd;
-        for (int di = wv; di < nd; di += 4) {
-          const int r = dlist[di];
-          unsigned long long kF, kP;
-          rescan_row(r, n, nw, lane, LV, IC, &kF, &kP);
-          if (lane == 0) {
-            bestF[r] = kF;
-            bestP[r] = kP;
-            atomicAnd(&stalew[r >> 5], ~(1u << (r & 31)));
-          }
-        }
+        rescan_list(dlist, s_nd, wv, lane, n, nw, LV, IC, bestF, bestP, stalew);
       }
       __syncthreads();
+#ifdef AHK_TIMING
+      {
+        const int Mh = s_items_last;
+        const int na_ = nA + nFa, nb_ = nB + nFb;
+        const int Th = na_ > nb_ ? na_ : nb_, Tl = na_ > nb_ ? nb_ : na_;
+        int bm = 0, bt = 0;
+        while (bm < 7 && Mh > (32 << bm)) bm++;
+        while (bt < 7 && Th > (2 << bt)) bt++;
+        const int bl = Tl <= 1 ? 0 : Tl <= 8 ? 1 : Tl <= 64 ? 2 : 3;
+        const long long tn = (long long)clock64();
+        hM[bm]++; hMc[bm] += tn - titer; hT[bt]++; hTc[bt] += tn - titer;
+        h2[bt * 4 + bl]++; h2c[bt * 4 + bl] += tn - titer; h2m[bt * 4 + bl] += Mh; titer = tn;
+        nmerge += merge ? 1 : 0; sumnd += s_nd;
+        heavy_it = false;
+      }
+#endif
       if (tid == 0) s_nd = 0;  // next append is behind the P1 reduction barrier
       AHK_T(4);
     }
@@ -857,6 +1025,15 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     if (tid == 0 && blockIdx.x == 0)
       printf("chain %d n=%d iters=%lld retries=%lld rescans=%lld sumT=%lld sumM=%lld sumW=%lld | cycles P1=%lld resc=%lld P2=%lld P3a=%lld (loadwait=%lld proc=%lld) P3b=%lld P4=%lld | P3b: decode=%lld tri=%lld fold=%lld\n", c, n, iters,
              nretry, nresc, sumT, sumM, (long long)s_chg, tacc[0], tacc[1], tacc[2], tacc[5], tacc[6], tacc[7], tacc[3], tacc[4], tacc[8], tacc[9], tacc[10]);
+    if (tid == 0 && blockIdx.x == 0) {
+      printf("merges=%lld sum_nd=%lld fast=%lld fast_cycles=%lld\n", nmerge, sumnd, nfast, tacc[11]);
+      printf("heavy iters=%lld | Mcycles P1=%lld P2=%lld P3a=%lld (loadwait=%lld proc=%lld) P3b=%lld P4=%lld | P3b: decode=%lld tri=%lld fold=%lld\n", nheavy, tacc2[0] / 1000000,
+             tacc2[2] / 1000000, tacc2[5] / 1000000, tacc2[6] / 1000000, tacc2[7] / 1000000, tacc2[3] / 1000000, tacc2[4] / 1000000, tacc2[8] / 1000000, tacc2[9] / 1000000, tacc2[10] / 1000000);
+      for (int b = 0; b < 8; b++)
+        for (int q = 0; q < 4; q++)
+          if (h2[b * 4 + q]) printf("ncmax<=%d ncmin_bucket=%d: iters=%lld Mcyc=%lld avgM=%lld\n", 2 << b, q, h2[b * 4 + q], h2c[b * 4 + q] / 1000000, h2m[b * 4 + q] / h2[b * 4 + q]);
+      for (int b = 0; b < 8; b++) printf("M<=%d: iters=%lld cyc/iter=%lld | T<=%d: iters=%lld cyc/iter=%lld\n", 32 << b, hM[b], hM[b] ? hMc[b] / hM[b] : 0, 2 << b, hT[b], hT[b] ? hTc[b] / hT[b] : 0);
+    }
 #endif
     if (lds.stop_after == 3) continue;
 
@@ -1105,7 +1282,7 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   size_t b = (size_t)l.nmax * 8 * 2;       // bestF, bestP
   b += (size_t)l.nmax * 2 * 5;             // cl + 4 lists
   b += (size_t)l.nmax * 2 * 5;             // rowbuf[4], dlist
-  b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4;  // stalew (padded to 8 bytes)
+  b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4 * 2;  // stalew, multiw (padded to 8 bytes)
   b += 2 * 4 * 32 * 8;                                   // rmask, rolenz
   b += (size_t)l.nmax;                     // role
   return (b + 15) & ~(size_t)15;
