@@ -64,12 +64,37 @@ __device__ __forceinline__ int icp_term(int p, int q) {
   if (p > 0 && q < 0) return nq < p ? nq : p;
   return 0;
 }
-// packed row-best key: larger value wins, then the smaller column
-__device__ __forceinline__ unsigned long long mkkey(long long val, int col) {
-  return ((unsigned long long)(val + 1) << 12) | (unsigned long long)(4095 - col);
+// Packed key of an edge (a,b), a < b, with induced cost val >= 0:
+//   (val+1) << 23 | stale << 22 | (2047-a) << 11 | (2047-b)
+// One unsigned 64-bit max picks the largest value and, among equal values, the
+// lexicographically smallest pair -- the heuristic's global tie rule.  Within one
+// row that is also "smallest other end", so the per-row maxima are kept in this
+// very form and the argmax is a plain max over them.  The stale bit marks a row
+// maximum that is only an upper bound (its edge went down or died): among equal
+// values a stale key wins the max, which is exactly "some stale row ties the
+// maximum -> rescan before deciding".  val+1 <= 2047 * 2^30 < 2^41 (weights are
+// clamped to 2^30, n <= 2048).  0 = no live edge.
+constexpr unsigned long long kStale = 1ull << 22;
+constexpr unsigned long long kPairMask = (1ull << 22) - 1ull;
+__device__ __forceinline__ unsigned long long mkkey(long long val, int r, int c) {
+  const unsigned int a = r < c ? r : c, b = r < c ? c : r;
+  return ((unsigned long long)(val + 1) << 23) | (unsigned long long)(((2047u - a) << 11) | (2047u - b));
 }
-__device__ __forceinline__ int key_col(unsigned long long k) { return 4095 - (int)(k & 4095ull); }
-__device__ __forceinline__ long long key_val(unsigned long long k) { return (long long)(k >> 12) - 1; }
+__device__ __forceinline__ long long key_val(unsigned long long k) { return (long long)(k >> 23) - 1; }
+__device__ __forceinline__ int key_a(unsigned long long k) { return 2047 - (int)((k >> 11) & 2047ull); }
+__device__ __forceinline__ int key_b(unsigned long long k) { return 2047 - (int)(k & 2047ull); }
+// the other end of the edge in key k, seen from its end r
+__device__ __forceinline__ int key_other(unsigned long long k, int r) {
+  const int a = key_a(k), b = key_b(k);
+  return a == r ? b : a;
+}
+// fold the new value of an edge into the maximum of the row of one of its ends:
+// a maximum that sat on this very edge and went down is now only an upper bound
+__device__ __forceinline__ void fold_key(unsigned long long* best, unsigned long long c) {
+  const unsigned long long k = *best;
+  if (((k ^ c) & kPairMask) == 0ull && c < (k & ~kStale)) atomicOr(best, kStale);
+  atomicMax(best, c);
+}
 
 // value of a 64-bit register in lane l, l wave-uniform (v_readlane, no LDS crossbar)
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
@@ -172,7 +197,8 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       if (col[c] < 0) continue;
-      const unsigned long long k1 = mkkey(v[c].f, col[c]), k2 = mkkey(v[c].p, col[c]);
+      const int rr = second[c] ? r1 : r0;
+      const unsigned long long k1 = mkkey(v[c].f, rr, col[c]), k2 = mkkey(v[c].p, rr, col[c]);
       if (second[c]) {
         kF1 = k1 > kF1 ? k1 : kF1;
         kP1 = k2 > kP1 ? k2 : kP1;
@@ -193,7 +219,7 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
 // rows dlist[0..nd): wave wv takes pairs of rows
 __device__ __forceinline__ void rescan_list(const unsigned short* dlist, int nd, int wv, int lane, int n, int nw,
                                             const unsigned long long* __restrict__ LV, const IcPair* __restrict__ IC,
-                                            unsigned long long* bestF, unsigned long long* bestP, unsigned int* stalew) {
+                                            unsigned long long* bestF, unsigned long long* bestP) {
   for (int di = 2 * wv; di < nd; di += 8) {
     const int r0 = dlist[di], r1 = di + 1 < nd ? (int)dlist[di + 1] : -1;
     unsigned long long keys[4];
@@ -201,11 +227,9 @@ __device__ __forceinline__ void rescan_list(const unsigned short* dlist, int nd,
     if (lane == 0) {
       bestF[r0] = keys[0];
       bestP[r0] = keys[1];
-      atomicAnd(&stalew[r0 >> 5], ~(1u << (r0 & 31)));
       if (r1 >= 0) {
         bestF[r1] = keys[2];
         bestP[r1] = keys[3];
-        atomicAnd(&stalew[r1 >> 5], ~(1u << (r1 & 31)));
       }
     }
   }
@@ -259,8 +283,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
   unsigned short* listFb = listFa + nmax;
   unsigned short* rowbuf = listFb + nmax;                 // [4][nmax] per-wave column buffers
   unsigned short* dlist = rowbuf + 4 * (size_t)nmax;      // [nmax] rows whose maximum must be rescanned
-  unsigned int* stalew = (unsigned int*)(dlist + nmax);   // [nmax/32] bit per row: already in dlist
-  unsigned int* multiw = stalew + ((nmax + 31) / 32 + 1) / 2 * 2;  // [nmax/32] bit per read: its clique has > 1 member
+  unsigned int* multiw = (unsigned int*)(dlist + nmax);   // [nmax/32] bit per read: its clique has > 1 member
   unsigned long long* rmask = (unsigned long long*)(multiw + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][32] role masks per 64-column word
   unsigned long long* rolenz = rmask + 4 * 32;             // [4][32] OR of the members' nz-rows
   unsigned char* role = (unsigned char*)(rolenz + 4 * 32);  // [nmax]
@@ -475,15 +498,16 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             v.p = p;
             IC[(unsigned)(a * n + b)] = v;
             IC[(unsigned)(b * n + a)] = v;
-            atomicMax(&bestF[a], mkkey(f, b));
-            atomicMax(&bestP[a], mkkey(p, b));
-            atomicMax(&bestF[b], mkkey(f, a));
-            atomicMax(&bestP[b], mkkey(p, a));
+            const unsigned long long kf = mkkey(f, a, b), kp = mkkey(p, a, b);
+            atomicMax(&bestF[a], kf);
+            atomicMax(&bestP[a], kp);
+            atomicMax(&bestF[b], kf);
+            atomicMax(&bestP[b], kp);
           }
         }
       }
     }
-    for (int u = tid; u < (n + 31) / 32; u += kBlock) { stalew[u] = 0; multiw[u] = 0; }
+    for (int u = tid; u < (n + 31) / 32; u += kBlock) multiw[u] = 0;
     if (tid < 4) s_cnt[tid] = 0;
     if (tid == 0) { s_nd = 0; s_items = 0; }
     __syncthreads();
@@ -509,61 +533,42 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       long long vf, vp;
       unsigned int abf, abp;
       for (;;) {
-        // global key of an edge: (value+1) << 22 | (2047-u) << 11 | (2047-v), u < v:
-        // one 64-bit max gives the largest value and, among equals, the
-        // lexicographically smallest pair.  value+1 < 2^42 (weights are clamped to
-        // 2^30, n <= 2048).  0 = no live edge.
-        unsigned long long gF = 0ull, gP = 0ull, tF = 0ull, tP = 0ull;
+        // the row maxima are packed edge keys (mkkey): the argmax with the
+        // heuristic's tie rule is one 64-bit max over them, and its stale bit says
+        // whether a stale bound ties the maximum
+        unsigned long long gF = 0ull, gP = 0ull;
         for (int u = tid; u < n; u += kBlock) {
           const unsigned long long k1 = bestF[u], k2 = bestP[u];
-          const bool st = (stalew[u >> 5] >> (u & 31)) & 1u;
-          if (k1) {
-            const int cc = key_col(k1);
-            const unsigned int a = u < cc ? u : cc, b = u < cc ? cc : u;
-            const unsigned long long g = ((k1 >> 12) << 22) | ((unsigned long long)(2047u - a) << 11) | (unsigned long long)(2047u - b);
-            gF = g > gF ? g : gF;
-            if (st && (k1 >> 12) > tF) tF = k1 >> 12;
-          }
-          if (k2) {
-            const int cc = key_col(k2);
-            const unsigned int a = u < cc ? u : cc, b = u < cc ? cc : u;
-            const unsigned long long g = ((k2 >> 12) << 22) | ((unsigned long long)(2047u - a) << 11) | (unsigned long long)(2047u - b);
-            gP = g > gP ? g : gP;
-            if (st && (k2 >> 12) > tP) tP = k2 >> 12;
-          }
+          gF = k1 > gF ? k1 : gF;
+          gP = k2 > gP ? k2 : gP;
         }
         gF = wave_max_u64(gF);
         gP = wave_max_u64(gP);
-        tF = wave_max_u64(tF);
-        tP = wave_max_u64(tP);
         if (lane == 0) {
-          s_rk[wv] = gF; s_rk[4 + wv] = gP; s_rk[8 + wv] = tF; s_rk[12 + wv] = tP;
+          s_rk[wv] = gF; s_rk[4 + wv] = gP;
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           gF = s_rk[k] > gF ? s_rk[k] : gF;
           gP = s_rk[4 + k] > gP ? s_rk[4 + k] : gP;
-          tF = s_rk[8 + k] > tF ? s_rk[8 + k] : tF;
-          tP = s_rk[12 + k] > tP ? s_rk[12 + k] : tP;
         }
-        vf = (long long)(gF >> 22) - 1;
-        vp = (long long)(gP >> 22) - 1;
-        abf = ((2047u - (unsigned)((gF >> 11) & 2047u)) << 16) | (2047u - (unsigned)(gF & 2047u));
-        abp = ((2047u - (unsigned)((gP >> 11) & 2047u)) << 16) | (2047u - (unsigned)(gP & 2047u));
-        const long long sF = (long long)tF - 1, sP = (long long)tP - 1;
-        const bool need = (sF >= 0 && sF == vf) || (sP >= 0 && sP == vp);
+        vf = key_val(gF);
+        vp = key_val(gP);
+        abf = ((unsigned)key_a(gF) << 16) | (unsigned)key_b(gF);
+        abp = ((unsigned)key_a(gP) << 16) | (unsigned)key_b(gP);
+        const bool need = ((gF | gP) & kStale) != 0ull;
         AHK_T(0);
         if (!need) break;  // uniform
         // collect the stale rows whose bound ties a maximum, rescan them exactly
         for (int u = tid; u < n; u += kBlock) {
-          if (!((stalew[u >> 5] >> (u & 31)) & 1u)) continue;
           const unsigned long long k1 = bestF[u], k2 = bestP[u];
-          if ((k1 && key_val(k1) == vf) || (k2 && key_val(k2) == vp)) dlist[atomicAdd(&s_nd, 1)] = (unsigned short)u;
+          if (((k1 & kStale) && (k1 >> 23) == (gF >> 23)) || ((k2 & kStale) && (k2 >> 23) == (gP >> 23)))
+            dlist[atomicAdd(&s_nd, 1)] = (unsigned short)u;
         }
         __syncthreads();
         {
-          rescan_list(dlist, s_nd, wv, lane, n, nw, LV, IC, bestF, bestP, stalew);
+          rescan_list(dlist, s_nd, wv, lane, n, nw, LV, IC, bestF, bestP);
         }
         __syncthreads();
 #ifdef AHK_TIMING
@@ -643,14 +648,12 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
               ic.p += dp;
               IC[ic_index(x, b, n)] = ic;
               IC[ic_index(b, x, n)] = ic;
-              const unsigned long long c1 = mkkey(ic.f, x), c2 = mkkey(ic.p, x);
-              const unsigned long long k1 = bestF[b], k2 = bestP[b];
-              if ((k1 && key_col(k1) == x && c1 < k1) || (k2 && key_col(k2) == x && c2 < k2))
-                atomicOr(&stalew[b >> 5], 1u << (b & 31));
-              atomicMax(&bestF[b], c1);
-              atomicMax(&bestP[b], c2);
             }
-            const unsigned long long r1 = mkkey(ic.f, b), r2 = mkkey(ic.p, b);
+            const unsigned long long r1 = mkkey(ic.f, x, b), r2 = mkkey(ic.p, x, b);
+            if (df != 0 || dp != 0) {
+              fold_key(&bestF[b], r1);
+              fold_key(&bestP[b], r2);
+            }
             kF = r1 > kF ? r1 : kF;
             kP = r2 > kP ? r2 : kP;
           }
@@ -664,7 +667,6 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           const unsigned long long a1 = s_rk[2 * tid], a2 = s_rk[2 * tid + 1], b1 = s_rk[4 + 2 * tid], b2 = s_rk[4 + 2 * tid + 1];
           bestF[xr] = a1 > a2 ? a1 : a2;
           bestP[xr] = b1 > b2 ? b1 : b2;
-          atomicAnd(&stalew[xr >> 5], ~(1u << (xr & 31)));
           Wm[(unsigned)(xr * n + (tid ? eu : ev))] = W_FORB;  // every wave has read the old weight by now
         }
         __syncthreads();
@@ -786,14 +788,11 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           bool hit = false;
           if (x >= 0) {
             const unsigned long long kF = bestF[x], kP = bestP[x];
-            const int cF = key_col(kF), cP = key_col(kP);
+            const int cF = key_other(kF, x), cP = key_other(kP, x);
             hit = (kF && kw == (cF >> 6) && ((D >> (cF & 63)) & 1ull)) || (kP && kw == (cP >> 6) && ((D >> (cP & 63)) & 1ull));
           }
           const unsigned long long hm = __ballot(hit) & segmask;
-          if (hm != 0ull && kw == 0 && x >= 0) {
-            atomicOr(&stalew[x >> 5], 1u << (x & 31));
-            dlist[atomicAdd(&s_nd, 1)] = (unsigned short)x;
-          }
+          if (hm != 0ull && kw == 0 && x >= 0) dlist[atomicAdd(&s_nd, 1)] = (unsigned short)x;
 #ifdef AHK_TIMING
           AHK_T(6);
 #endif
@@ -932,20 +931,11 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           // fold the new value into both row maxima; a maximum that sat on this
           // edge and went down is now only an upper bound -> mark the row stale
           {
-            const unsigned long long c1 = mkkey(ic.f, b), c2 = mkkey(ic.p, b);
-            const unsigned long long k1 = bestF[x], k2 = bestP[x];
-            if ((k1 && key_col(k1) == b && c1 < k1) || (k2 && key_col(k2) == b && c2 < k2))
-              atomicOr(&stalew[x >> 5], 1u << (x & 31));
-            atomicMax(&bestF[x], c1);
-            atomicMax(&bestP[x], c2);
-          }
-          {
-            const unsigned long long c1 = mkkey(ic.f, x), c2 = mkkey(ic.p, x);
-            const unsigned long long k1 = bestF[b], k2 = bestP[b];
-            if ((k1 && key_col(k1) == x && c1 < k1) || (k2 && key_col(k2) == x && c2 < k2))
-              atomicOr(&stalew[b >> 5], 1u << (b & 31));
-            atomicMax(&bestF[b], c1);
-            atomicMax(&bestP[b], c2);
+            const unsigned long long c1 = mkkey(ic.f, x, b), c2 = mkkey(ic.p, x, b);
+            fold_key(&bestF[x], c1);
+            fold_key(&bestP[x], c2);
+            fold_key(&bestF[b], c1);
+            fold_key(&bestP[b], c2);
           }
 #ifdef AHK_TIMING
           AHK_T(10);
@@ -998,7 +988,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         if (tid < 4) s_cnt[tid] = 0;
         if (tid == 0) s_items = 0;
         // rows whose maximum died: exact rescan now (they would tie the next argmax anyway)
-        rescan_list(dlist, s_nd, wv, lane, n, nw, LV, IC, bestF, bestP, stalew);
+        rescan_list(dlist, s_nd, wv, lane, n, nw, LV, IC, bestF, bestP);
       }
       __syncthreads();
 #ifdef AHK_TIMING
@@ -1282,7 +1272,7 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   size_t b = (size_t)l.nmax * 8 * 2;       // bestF, bestP
   b += (size_t)l.nmax * 2 * 5;             // cl + 4 lists
   b += (size_t)l.nmax * 2 * 5;             // rowbuf[4], dlist
-  b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4 * 2;  // stalew, multiw (padded to 8 bytes)
+  b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4;  // multiw (padded to 8 bytes)
   b += 2 * 4 * 32 * 8;                                   // rmask, rolenz
   b += (size_t)l.nmax;                     // role
   return (b + 15) & ~(size_t)15;
