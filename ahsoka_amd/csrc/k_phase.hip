@@ -157,7 +157,6 @@ __device__ __forceinline__ int new_w(int r1, int r2, bool merge) {
 // the second, scattered store.  (A single copy at [min][max] made half of all
 // reads column accesses: one HBM line per 16 useful bytes.)
 __device__ __forceinline__ unsigned ic_index(int r, int c, int n) { return (unsigned)(r * n + c); }
-
 // Exact maxima of rows r0 and r1 (r1 < 0: none) over their live edges.  Lane = bit
 // of a 64-column bitmap word; the non-empty words of both rows form one work list
 // that is consumed four words at a time: the four induced-cost loads of a batch are
@@ -767,19 +766,32 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         }
         const unsigned long long Tm = mA | mB | mFa | mFb;
         const unsigned long long segmask = (nwp == 64 ? ~0ull : ((1ull << nwp) - 1ull)) << (slot << nwp_log);
+        auto row_of = [&](int xi) -> int {
+          if (xi >= nT) return -1;
+          if (xi < nA) return listA[xi];
+          if (xi < nA + nB) return listB[xi - nA];
+          if (xi < nA + nB + nFa) return listFa[xi - nA - nB];
+          return listFb[xi - nA - nB - nFa];
+        };
+        // the bitmap words of pass k+1 are requested before pass k is processed: with
+        // hundreds of rewritten rows (a large clique) every pass would otherwise wait
+        // for its own HBM round trip
+        int x_nx = row_of(wv * RP + slot);
+        unsigned long long lv_nx = 0ull, nz_nx = 0ull;
+        if (x_nx >= 0 && wordok) {
+          lv_nx = LV[(unsigned)(x_nx * nw + kw)];
+          nz_nx = NZ[(unsigned)(x_nx * nw + kw)];
+        }
         for (int xi0 = wv * RP; xi0 < nT; xi0 += 4 * RP) {
           const int xi = xi0 + slot;
-          int x = -1;
-          if (xi < nT) {
-            if (xi < nA) x = listA[xi];
-            else if (xi < nA + nB) x = listB[xi - nA];
-            else if (xi < nA + nB + nFa) x = listFa[xi - nA - nB];
-            else x = listFb[xi - nA - nB - nFa];
-          }
-          unsigned long long lvw = 0ull, nzw = 0ull;
-          if (x >= 0 && wordok) {
-            lvw = LV[(unsigned)(x * nw + kw)];
-            nzw = NZ[(unsigned)(x * nw + kw)];
+          const int x = x_nx;
+          const unsigned long long lvw = lv_nx, nzw = nz_nx;
+          x_nx = row_of(xi + 4 * RP);
+          lv_nx = 0ull;
+          nz_nx = 0ull;
+          if (x_nx >= 0 && wordok) {
+            lv_nx = LV[(unsigned)(x_nx * nw + kw)];
+            nz_nx = NZ[(unsigned)(x_nx * nw + kw)];
           }
           // the role of x follows from which list it came from
           const int rx = xi < nA ? ROLE_A : xi < nA + nB ? ROLE_B : xi < nA + nB + nFa ? ROLE_FA : ROLE_FB;
