@@ -176,6 +176,8 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
     for (int c = 0; c < 4; c++) {
       col[c] = -1;
       second[c] = false;
+      v[c].f = 0;  // (defined on every path: an undefined value becomes a register that lives across the caller's loop)
+      v[c].p = 0;
       int l = -1;
       unsigned long long w = 0ull;
       if (todo0 != 0ull) {
@@ -209,6 +211,8 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
   }
   keys[0] = wave_max_u64(kF0);
   keys[1] = wave_max_u64(kP0);
+  keys[2] = 0ull;  // (always defined: an undefined value here becomes a register that lives across the whole main loop)
+  keys[3] = 0ull;
   if (r1 >= 0) {
     keys[2] = wave_max_u64(kF1);
     keys[3] = wave_max_u64(kP1);
@@ -624,6 +628,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           for (int c = 0; c < 2; c++) {
             on[c] = false;
             wb[c] = 0;
+            icv[c].f = 0;  // (defined on every path, see rescan_rows2)
+            icv[c].p = 0;
             if (lw[c] >= 0) {
               const unsigned long long wd = readlane_u64(lvn, lw[c]);
               const unsigned long long cd = wd & readlane_u64(nzo, lw[c]);

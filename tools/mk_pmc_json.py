@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""gpurun_out/<tag>_pmc.txt (tools/pmc.sh output) -> profiles/<tag>_pmc_hbm.json"""
+import json, sys
+tag, config, chains = sys.argv[1], sys.argv[2], int(sys.argv[3])
+k = {}
+for line in open(f"gpurun_out/{tag}_pmc.txt"):
+    p = line.split()
+    if len(p) == 4 and p[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+        name = "k_phase" if "k_phase" in p[1] else "k_readset"
+        k.setdefault(name, {})[p[0] + "_KB"] = float(p[3])
+for v in k.values():
+    v["hbm_bytes_raw"] = (v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024
+    v["hbm_bytes_fetch_x2"] = (2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024
+out = {
+    "what": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh), python3 bench.py --chains {chains} --steps 1 --warmup 0 (BASELINE configs[2], one launch of each kernel)",
+    "config": config, "chains": chains,
+    "note": "hbm_bytes_fetch_x2 = (2*FETCH_SIZE + WRITE_SIZE)*1024 is the calibrated reading: FETCH_SIZE tallies 64 B per 128-B request on gfx950, for scattered 4/16-B reads as for wide streams (profiles/r01_fetch_calibration.json)",
+    "kernels": k,
+}
+json.dump(out, open(f"profiles/{tag}_pmc_hbm.json", "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))
