@@ -269,6 +269,10 @@ __device__ __forceinline__ void pair_overlap(const ChainCtx& cx, int i, int j, i
 // global_load/global_store.  Read through a pointer-to-struct they degrade to
 // flat_* instructions, which count on lgkmcnt as well -- every LDS wait then
 // also waits for all outstanding HBM traffic (measured: whole-kernel slowdown).
+#ifndef AHK_FAST_BATCH
+#define AHK_FAST_BATCH 4
+#endif
+constexpr int kFastBatch = AHK_FAST_BATCH;  // live words of a row a wave of the fast path loads together
 #ifndef AHK_WAVES_PER_SIMD
 #define AHK_WAVES_PER_SIMD 5
 #endif
@@ -436,6 +440,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       role[u] = ROLE_NONE;
     }
     __syncthreads();
+
+    if (lds.stop_after == 1) continue;  // profiling aid only (results invalid)
 
     // ================= S5 init: induced costs of every live edge ===========
     // icf(ab) = max(w_ab,0) + sum_w min(w_aw,w_bw)+ ; icp likewise.  One wave per
@@ -611,21 +617,21 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         }
         unsigned long long todo = __ballot(lvn != 0ull);
         unsigned long long kF = 0ull, kP = 0ull;
-        // this wave takes the live words of even (sub 0) / odd (sub 1) rank, two per trip
+        // this wave takes the live words of even (sub 0) / odd (sub 1) rank, kFastBatch per trip
         while (todo != 0ull) {
-          int lw[2];
+          int lw[kFastBatch];
 #pragma unroll
-          for (int c = 0; c < 2; c++) {
+          for (int c = 0; c < kFastBatch; c++) {
             if (sub && todo != 0ull) todo &= todo - 1ull;
             lw[c] = todo != 0ull ? __builtin_ctzll(todo) : -1;
             if (todo != 0ull) todo &= todo - 1ull;
             if (!sub && todo != 0ull) todo &= todo - 1ull;
           }
-          IcPair icv[2];
-          int wb[2];
-          bool on[2];
+          IcPair icv[kFastBatch];
+          int wb[kFastBatch];
+          bool on[kFastBatch];
 #pragma unroll
-          for (int c = 0; c < 2; c++) {
+          for (int c = 0; c < kFastBatch; c++) {
             on[c] = false;
             wb[c] = 0;
             icv[c].f = 0;  // (defined on every path, see rescan_rows2)
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             }
           }
 #pragma unroll
-          for (int c = 0; c < 2; c++) {
+          for (int c = 0; c < kFastBatch; c++) {
             if (!on[c]) continue;
             const int b = (lw[c] << 6) + lane;
             IcPair ic = icv[c];
