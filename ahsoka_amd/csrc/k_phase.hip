@@ -26,6 +26,8 @@
 // edge-by-edge sequential loop bit for bit.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "detmath.h"
 #include "gnusort.h"
 #include "phase_kernels.h"
@@ -273,6 +275,16 @@ __device__ __forceinline__ void pair_overlap(const ChainCtx& cx, int i, int j, i
 #define AHK_FAST_BATCH 4
 #endif
 constexpr int kFastBatch = AHK_FAST_BATCH;  // live words of a row a wave of the fast path loads together
+#ifndef AHK_P3B_FULL
+#define AHK_P3B_FULL 1
+#endif
+#ifndef AHK_P3B_SPECIAL
+#define AHK_P3B_SPECIAL 1
+#endif
+#ifndef AHK_P3B_CH
+#define AHK_P3B_CH 4
+#endif
+constexpr int kP3bChunk = AHK_P3B_CH;  // triangles per load batch of an edge in P3b
 #ifndef AHK_WAVES_PER_SIMD
 #define AHK_WAVES_PER_SIMD 5
 #endif
@@ -817,7 +829,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           }
           const unsigned long long hm = __ballot(hit) & segmask;
           if (hm != 0ull && kw == 0 && x >= 0) dlist[atomicAdd(&s_nd, 1)] = (unsigned short)x;
-#ifdef AHK_TIMING
+#if defined(AHK_TIMING) && AHK_TIMING > 1
           AHK_T(6);
 #endif
           unsigned long long cand = 0ull;
@@ -859,7 +871,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
               base += __popcll(w);
             }
           }
-#ifdef AHK_TIMING
+#if defined(AHK_TIMING) && AHK_TIMING > 1
           AHK_T(7);
 #endif
         }
@@ -886,7 +898,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           // cuts the loop's HBM lines by a quarter -- the loop is latency-bound
           IcPair ic = IC[ici];
           long long df = 0, dp = 0;
-#ifdef AHK_TIMING
+#if defined(AHK_TIMING) && AHK_TIMING > 1
           AHK_T(8);
 #endif
           {
@@ -894,12 +906,65 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             const int n1 = (rx == ROLE_A || rx == ROLE_FA) ? nB : nA;
             const unsigned short* L2 = rx == ROLE_A ? listFb : listFa;
             const int n2 = rx == ROLE_A ? nFb : (rx == ROLE_B ? nFa : 0);
-            const int nc = n1 + n2;
-            for (int w0 = 0; w0 < nc; w0 += 4) {
-              // the sixteen loads of a chunk of eight triangles are independent
-              int ws4[4], ov4[4], wb4[4];
+#if AHK_P3B_SPECIAL
+            if (rb == ROLE_NONE) {
+              // The common case: b is not itself rewritten, so the third edge (w,b) keeps
+              // its weight, and within one member list the new weight of (x,w) is one
+              // constant -- W_PERM for the opposite clique of a merge, W_FORB otherwise.
+              // With that constant known at compile time the two "new" terms fold to
+              // max(q,0) / max(-q,0) / 0: about half the instructions per triangle.
+              // (Padding slots load nothing and read as 0,0: all four terms vanish.)
+              auto seg = [&](auto nv_tag, const unsigned short* L, int cnt) {
+                constexpr int Nv = decltype(nv_tag)::value;
+                int w0 = 0;
+#if AHK_P3B_FULL
+                // full chunks: no per-load predicate (each one costs an exec-mask branch),
+                // the four member ids come with one 8-byte LDS read
+                static_assert(kP3bChunk == 4, "full-chunk loop reads four u16 ids at once");
+                for (; w0 + 4 <= cnt; w0 += 4) {
+                  const uint2 pk = *reinterpret_cast<const uint2*>(L + w0);
+                  const int wq[4] = {(int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16)};
+                  int ovv[4], wbv[4];
 #pragma unroll
-              for (int c = 0; c < 4; c++) {
+                  for (int c = 0; c < 4; c++) {
+                    ovv[c] = Wm[(unsigned)(x * n + wq[c])];
+                    wbv[c] = Wm[(unsigned)(wq[c] * n + b)];
+                  }
+#pragma unroll
+                  for (int c = 0; c < 4; c++) {
+                    df += icf_term(Nv, wbv[c]) - icf_term(ovv[c], wbv[c]);
+                    dp += icp_term(Nv, wbv[c]) - icp_term(ovv[c], wbv[c]);
+                  }
+                }
+#endif
+                for (; w0 < cnt; w0 += kP3bChunk) {
+                  int ovv[kP3bChunk], wbv[kP3bChunk];
+#pragma unroll
+                  for (int c = 0; c < kP3bChunk; c++) {
+                    const bool ok = w0 + c < cnt;
+                    const int w = ok ? (int)L[w0 + c] : 0;
+                    ovv[c] = ok ? Wm[(unsigned)(x * n + w)] : 0;
+                    wbv[c] = ok ? Wm[(unsigned)(w * n + b)] : 0;
+                  }
+#pragma unroll
+                  for (int c = 0; c < kP3bChunk; c++) {
+                    df += icf_term(Nv, wbv[c]) - icf_term(ovv[c], wbv[c]);
+                    dp += icp_term(Nv, wbv[c]) - icp_term(ovv[c], wbv[c]);
+                  }
+                }
+              };
+              if (merge && (rx == ROLE_A || rx == ROLE_B)) seg(std::integral_constant<int, W_PERM>{}, L1, n1);
+              else seg(std::integral_constant<int, W_FORB>{}, L1, n1);
+              if (n2 > 0) seg(std::integral_constant<int, W_FORB>{}, L2, n2);
+            } else
+#endif
+            {
+            const int nc = n1 + n2;
+            for (int w0 = 0; w0 < nc; w0 += kP3bChunk) {
+              // the sixteen loads of a chunk of eight triangles are independent
+              int ws4[kP3bChunk], ov4[kP3bChunk], wb4[kP3bChunk];
+#pragma unroll
+              for (int c = 0; c < kP3bChunk; c++) {
                 const int wi = w0 + c;
                 const int w = wi < n1 ? L1[wi] : (wi < nc ? L2[wi - n1] : -1);
                 ws4[c] = w;
@@ -907,7 +972,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
                 wb4[c] = w >= 0 ? Wm[(unsigned)(w * n + b)] : 0;
               }
 #pragma unroll
-              for (int c = 0; c < 4; c++) {
+              for (int c = 0; c < kP3bChunk; c++) {
                 const int w = ws4[c];
                 if (w < 0) continue;
                 // the role of w follows from the list it sits in
@@ -918,6 +983,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
                 df += icf_term(Nv, wbn) - icf_term(ov4[c], wbo);
                 dp += icp_term(Nv, wbn) - icp_term(ov4[c], wbo);
               }
+            }
             }
           }
           if (rb != ROLE_NONE) {
@@ -941,7 +1007,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
               }
             }
           }
-#ifdef AHK_TIMING
+#if defined(AHK_TIMING) && AHK_TIMING > 1
           AHK_T(9);
 #endif
           if (df == 0 && dp == 0) continue;
@@ -961,14 +1027,11 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             fold_key(&bestF[b], c1);
             fold_key(&bestP[b], c2);
           }
-#ifdef AHK_TIMING
+#if defined(AHK_TIMING) && AHK_TIMING > 1
           AHK_T(10);
 #endif
         }
       }
-#ifdef AHK_TIMING
-      AHK_T(10);
-#endif
       __syncthreads();
       AHK_T(3);
 
@@ -1028,11 +1091,13 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         hM[bm]++; hMc[bm] += tn - titer; hT[bt]++; hTc[bt] += tn - titer;
         h2[bt * 4 + bl]++; h2c[bt * 4 + bl] += tn - titer; h2m[bt * 4 + bl] += Mh; titer = tn;
         nmerge += merge ? 1 : 0; sumnd += s_nd;
-        heavy_it = false;
       }
 #endif
       if (tid == 0) s_nd = 0;  // next append is behind the P1 reduction barrier
       AHK_T(4);
+#ifdef AHK_TIMING
+      heavy_it = false;
+#endif
     }
     __syncthreads();
 #ifdef AHK_TIMING
