@@ -49,6 +49,11 @@
 #define AHK_T(slot) do {} while (0)
 #endif
 
+// tuning switches (tools/variants.sh builds and benches combinations on one box)
+#ifndef AHK_MINMAX_TERMS
+#define AHK_MINMAX_TERMS 1
+#endif
+
 namespace ahk {
 
 constexpr int ROLE_NONE = 0, ROLE_A = 1, ROLE_B = 2, ROLE_FA = 3, ROLE_FB = 4;
@@ -57,6 +62,20 @@ constexpr int ROLE_NONE = 0, ROLE_A = 1, ROLE_B = 2, ROLE_FA = 3, ROLE_FB = 4;
 // under min/negation.  (A term with BOTH edges infinite never reaches a live
 // edge: the third edge of such a triangle is already implied.)
 __device__ __forceinline__ int wval(int w) { return w; }
+// (min/max forms of: "both positive -> the smaller", and "opposite signs -> the smaller
+// magnitude"; two and five VALU instructions, no compares.  Inputs are never INT_MIN.)
+#if AHK_MINMAX_TERMS
+__device__ __forceinline__ int icf_term(int p, int q) {
+  const int m = p < q ? p : q;
+  return m > 0 ? m : 0;
+}
+__device__ __forceinline__ int icp_term(int p, int q) {
+  const int np = -p, nq = -q;
+  const int a = np < q ? np : q, b = p < nq ? p : nq;
+  const int m = a > b ? a : b;
+  return m > 0 ? m : 0;
+}
+#else
 __device__ __forceinline__ int icf_term(int p, int q) {
   return (p > 0 && q > 0) ? (p < q ? p : q) : 0;
 }
@@ -66,6 +85,7 @@ __device__ __forceinline__ int icp_term(int p, int q) {
   if (p > 0 && q < 0) return nq < p ? nq : p;
   return 0;
 }
+#endif
 // Packed key of an edge (a,b), a < b, with induced cost val >= 0:
 //   (val+1) << 23 | stale << 22 | (2047-a) << 11 | (2047-b)
 // One unsigned 64-bit max picks the largest value and, among equal values, the
