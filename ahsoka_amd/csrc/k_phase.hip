@@ -512,28 +512,37 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             NZ[(unsigned)(a * nw + (w0 >> 6))] = mk;
           }
         }
+        // lanes = the neighbours b > a.  The row's own weights W[a][w] are wave-uniform:
+        // 64 of them are fetched with ONE load (lane = neighbour index) and handed out
+        // with v_readlane -- as scalar operands -- instead of 64 uniform loads; padding
+        // neighbours read as weight 0 (both terms vanish), so nothing is predicated.
         for (int i0 = 0; i0 < dhi; i0 += 64) {
           const int i = i0 + lane;
-          if (i < dhi) {
-            const int b = nhi[i];
-            const int wab = Wm[(unsigned)(a * n + b)];
-            long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
-            // eight triangles per trip: their sixteen loads are independent and in
-            // flight together (a one-load-per-trip loop here is pure HBM/L2 latency)
-            for (int w0 = 0; w0 < deg; w0 += 8) {
-              int wa[8], wb[8];
+          const bool act = i < dhi;
+          const int b = act ? (int)nhi[i] : a;
+          const int wab = Wm[(unsigned)(a * n + b)];  // (a,a) is 0
+          long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
+          for (int k0 = 0; k0 < deg; k0 += 64) {
+            const int kk = k0 + lane;
+            const int nb_l = kk < deg ? (int)nbr[kk] : a;
+            const int wa_l = Wm[(unsigned)(a * n + nb_l)];
+            const int cnt = deg - k0 < 64 ? deg - k0 : 64;
+            for (int c0 = 0; c0 < cnt; c0 += 8) {
+              int wb[8];
 #pragma unroll
               for (int c = 0; c < 8; c++) {
-                const int w = nbr[w0 + c < deg ? w0 + c : 0];
-                wa[c] = w0 + c < deg ? Wm[(unsigned)(a * n + w)] : 0;  // wave-uniform
-                wb[c] = w0 + c < deg ? Wm[(unsigned)(w * n + b)] : 0;
+                const int w = __builtin_amdgcn_readlane(nb_l, c0 + c);
+                wb[c] = Wm[(unsigned)(w * n + b)];
               }
 #pragma unroll
               for (int c = 0; c < 8; c++) {
-                f += icf_term(wa[c], wb[c]);
-                p += icp_term(wa[c], wb[c]);
+                const int wa = __builtin_amdgcn_readlane(wa_l, c0 + c);
+                f += icf_term(wa, wb[c]);
+                p += icp_term(wa, wb[c]);
               }
             }
+          }
+          if (act) {
             IcPair v;
             v.f = f;
             v.p = p;
