@@ -1103,8 +1103,10 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         }
         if (tid < 4) s_cnt[tid] = 0;
         if (tid == 0) s_items = 0;
+        AHK_T(6);  // (diagnostic build: weight rewrites vs rescans)
         // rows whose maximum died: exact rescan now (they would tie the next argmax anyway)
         rescan_list(dlist, s_nd, wv, lane, n, nw, LV, IC, bestF, bestP);
+        AHK_T(7);
       }
       __syncthreads();
 #ifdef AHK_TIMING
@@ -1135,7 +1137,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
              nretry, nresc, sumT, sumM, (long long)s_chg, tacc[0], tacc[1], tacc[2], tacc[5], tacc[6], tacc[7], tacc[3], tacc[4], tacc[8], tacc[9], tacc[10]);
     if (tid == 0 && blockIdx.x == 0) {
       printf("merges=%lld sum_nd=%lld fast=%lld fast_cycles=%lld\n", nmerge, sumnd, nfast, tacc[11]);
-      printf("heavy iters=%lld | Mcycles P1=%lld P2=%lld P3a=%lld (loadwait=%lld proc=%lld) P3b=%lld P4=%lld | P3b: decode=%lld tri=%lld fold=%lld\n", nheavy, tacc2[0] / 1000000,
+      printf("heavy iters=%lld | Mcycles P1=%lld P2=%lld P3a=%lld (P4: rewrite=%lld rescan=%lld) P3b=%lld P4wait=%lld | P3b: decode=%lld tri=%lld fold=%lld\n", nheavy, tacc2[0] / 1000000,
              tacc2[2] / 1000000, tacc2[5] / 1000000, tacc2[6] / 1000000, tacc2[7] / 1000000, tacc2[3] / 1000000, tacc2[4] / 1000000, tacc2[8] / 1000000, tacc2[9] / 1000000, tacc2[10] / 1000000);
       for (int b = 0; b < 8; b++)
         for (int q = 0; q < 4; q++)
