@@ -95,8 +95,10 @@ def main():
         if world > 1:
             # the one collective of the path: every rank's packed result block
             # (device memory, fixed layout) to rank 0 -- RCCL gather over xGMI
+            # (.clone(): the collective then works on memory torch itself allocated; the
+            # library's block lives in the system HIP runtime's allocation table)
             block = dev.result_tensor()
-            gathered = shard.gather_device_blocks(block if backend == "nccl" else block.cpu())
+            gathered = shard.gather_device_blocks(block.clone() if backend == "nccl" else block.cpu())
         return res, gathered
 
     def fence():
