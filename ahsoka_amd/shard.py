@@ -175,6 +175,32 @@ def gather_device_blocks(block, group=None):
     return bufs
 
 
+def pack_block(res: PhaseResult, bubble_off: np.ndarray) -> np.ndarray:
+    """Host mirror of the device result block (``ahsoka_batch_result_device``): int32
+    ``[status[C] | npos[C] | pos[SB] | hap[ploidy*SB]]`` with SB = bubble_off[-1]; chain c
+    owns pos[bubble_off[c]:][:npos] and hap[ploidy*bubble_off[c]:][:ploidy*npos] (ploidy rows
+    of npos alleles), the rest is padding (-1 here, unspecified in the device block).  The layout depends only on the batch shape,
+    so equal shards give equal block lengths on every rank."""
+    p = res.ploidy
+    C = res.n_chains
+    SB = int(bubble_off[-1])
+    blk = np.full(2 * C + SB + p * SB, -1, dtype=np.int32)
+    npos = np.diff(res.pos_off).astype(np.int64)
+    blk[:C] = res.status
+    blk[C:2 * C] = npos
+    total = int(res.pos_off[-1])
+    if total:
+        row = np.repeat(np.arange(C), npos)
+        col = np.arange(total) - np.repeat(res.pos_off[:-1], npos)
+        blk[2 * C + bubble_off[:-1][row] + col] = res.pos
+        base_in = p * np.repeat(res.pos_off[:-1], npos)
+        base_out = 2 * C + SB + p * bubble_off[:-1][row]
+        Prep = np.repeat(npos, npos)
+        for i in range(p):
+            blk[base_out + i * Prep + col] = res.hap_allele[base_in + i * Prep + col]
+    return blk
+
+
 def decode_block(block: np.ndarray, bubble_off: np.ndarray, ploidy: int):
     """host view of one packed block -> (status, pos_off, pos, hap_allele) like PhaseResult"""
     C = len(bubble_off) - 1

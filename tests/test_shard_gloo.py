@@ -40,6 +40,67 @@ def _worker(rank, world, port, cfg, q):
     dist.destroy_process_group()
 
 
+def _worker_blocks(rank, world, port, cfg, q):
+    """the bench's N > 1 step: fixed-layout result blocks, one gather, decode on rank 0"""
+    import torch
+    import torch.distributed as dist
+
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ahsoka_amd import capi, shard
+    import oracle_binding as ob
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = cfg["n_chains"] // world
+    mine = dict(cfg)
+    mine["n_chains"] = per
+    mine["first_chain"] = rank * per
+    b = capi.synth_batch(**mine)
+    boff = b.arrays()["bubble_off"]
+    res = ob.phase_batch(b, capi.default_params(ploidy=cfg["ploidy"]))
+    blocks = shard.gather_device_blocks(torch.from_numpy(shard.pack_block(res, boff)))
+    if rank == 0:
+        out = []
+        for r, blk in enumerate(blocks):
+            c = dict(cfg)
+            c["n_chains"] = per
+            c["first_chain"] = r * per
+            out.append(shard.decode_block(blk.numpy(), capi.synth_batch(**c).arrays()["bubble_off"], cfg["ploidy"]))
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_block_gather():
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ahsoka_amd import capi
+    import oracle_binding as ob
+
+    cfg = dict(n_chains=8, n_bubbles=6, n_reads=60, ploidy=2, seed=78)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_blocks, args=(r, 2, port, cfg, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    parts = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = ob.phase_batch(capi.synth_batch(**cfg), capi.default_params())
+    status = np.concatenate([x[0] for x in parts])
+    pos = np.concatenate([x[2] for x in parts])
+    hap = np.concatenate([x[3] for x in parts])
+    np.testing.assert_array_equal(status, ref.status)
+    np.testing.assert_array_equal(pos, ref.pos)
+    np.testing.assert_array_equal(hap, ref.hap_allele)
+
+
 @pytest.mark.parametrize("total", [7, 10])
 def test_two_ranks_equal_one_process(total):
     for p in (ROOT, os.path.join(ROOT, "tests")):
