@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Extended differential soak (not collected by pytest): GPU vs CPU oracle, all stages, on many
+more random irregular batches and synthetic shapes than the regular suite runs.
+
+    python tests/soak_gpu.py [n_random] [n_shapes]
+
+Prints one line per 10 cases and a final verdict; exits non-zero on the first mismatch."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from ahsoka_amd import capi  # noqa: E402
+import oracle_binding as ob  # noqa: E402
+from random_batches import random_batch  # noqa: E402
+from test_gpu_parity import _compare  # noqa: E402
+
+
+def main():
+    n_random = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    n_shapes = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    rng = np.random.default_rng(20261004)
+    done = 0
+    for k in range(n_random):
+        b = random_batch(50000 + k)
+        _compare(b, capi.default_params(want_stages=1, min_mapq=int(rng.choice([90, 93, 95])),
+                                        compaction_mode=int(k % 2)))
+        done += 1
+        if done % 10 == 0:
+            print(f"{done} cases ok", flush=True)
+    for k in range(n_shapes):
+        nb = int(rng.integers(2, 120))
+        nr = int(rng.integers(10, 1600))
+        ploidy = int(rng.choice([2, 2, 2, 3, 4]))
+        if ploidy > 2:
+            nr = min(nr, 500)
+            nb = min(nb, 24)
+        nc = 3 if nr > 800 else 6
+        b = capi.synth_batch(n_chains=nc, n_bubbles=nb, n_reads=nr, ploidy=ploidy, seed=7000 + k,
+                             mean_span=float(rng.choice([3.0, 7.0, 15.0])), allele_err=float(rng.choice([0.0, 0.02, 0.15])))
+        _compare(b, capi.default_params(ploidy=ploidy, want_stages=1))
+        done += 1
+        if done % 10 == 0:
+            print(f"{done} cases ok (shape {nc}x{nb}x{nr} p{ploidy})", flush=True)
+    print(f"SOAK OK: {done} cases bit-identical to the oracle")
+
+
+if __name__ == "__main__":
+    main()
