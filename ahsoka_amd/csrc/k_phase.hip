@@ -50,6 +50,9 @@
 #endif
 
 // tuning switches (tools/variants.sh builds and benches combinations on one box)
+#ifndef AHK_DPP_SUM
+#define AHK_DPP_SUM 1
+#endif
 #ifndef AHK_MINMAX_TERMS
 #define AHK_MINMAX_TERMS 1
 #endif
@@ -129,16 +132,29 @@ __device__ __forceinline__ int mask_rank(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
 }
 
+// sum over the 64 lanes, result in every lane: DPP row shifts / row broadcasts (VALU only;
+// __shfl_xor would be six trips through the LDS crossbar)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_add_step(int v) {
+  return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xf, false);
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
+#if AHK_DPP_SUM
+  v = dpp_add_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row sum
+  v = dpp_add_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the sum
+  return __builtin_amdgcn_readlane(v, 63);
+#else
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+#endif
 }
-__device__ __forceinline__ long long wave_sum_ll(long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+// (for sums known to stay below 2^31: the S4a counters are at most 1023 per pair)
+__device__ __forceinline__ long long wave_sum_ll(long long v) { return (long long)wave_sum_i((int)v); }
 // max over the 64 lanes, result in every lane.  DPP row shifts / row broadcasts
 // run in the VALU (a few cycles each); __shfl_xor would go through the LDS
 // crossbar (ds_bpermute, ~100 cycles a step).  0 is the identity.
