@@ -141,6 +141,8 @@ def main():
         alg_bytes = batch.algorithmic_input_bytes(ploidy) + 4 * (P_total + ploidy * P_total + n_phased)
         kp = float(np.mean(k_phase_ms))
         achieved = alg_bytes / (kp * 1e-3) / 1e9
+        traffic = pmc_traffic(args.config, per_gpu)
+        stream = stream_copy_gbps(torch, device)
         out = {
             "metric": "bubbles/s phased (ploidy 2, 1000 reads/chain)",
             "value": value,
@@ -168,10 +170,14 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.config, per_gpu),
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": kp,
                 "k_readset_ms": float(np.mean(k_readset_ms)),
+                # the measured traffic (committed PMC summary of this workload) over this run's kernel
+                # time, against the nominal peak and against a streaming copy measured in this job
+                "traffic_rate_GBps": (traffic / (kp * 1e-3) / 1e9) if traffic else None,
+                "stream_copy_GBps": stream,
             },
             "phased_bubbles_per_step": total_phased,
             "phased_chains_rank0": n_phased,
@@ -188,6 +194,27 @@ def main():
         dist.destroy_process_group()
 
 
+def stream_copy_gbps(torch, device):
+    """STREAM-style device copy: read + write bytes per second of a plain
+    1 GiB -> 1 GiB copy on this GPU, measured in the same job; the yardstick for what the
+    HBM can deliver to a perfectly streaming kernel."""
+    n = 1 << 28  # int32 elements = 1 GiB
+    a = torch.empty(n, dtype=torch.int32, device=device).fill_(1)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    return 2.0 * n * 4 / (ms * 1e-3) / 1e9
+
+
 def pmc_traffic(config, chains):
     """HBM bytes of one k_phase launch from the committed rocprofv3 PMC summary
     (tools/pmc.sh, separate FETCH_SIZE / WRITE_SIZE passes) of this very workload;
@@ -195,7 +222,13 @@ def pmc_traffic(config, chains):
     the gfx950 half-count of FETCH_SIZE was calibrated on scattered 4- and 16-byte
     reads as well (profiles/r01_fetch_calibration.json): 64 B tallied per request."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    import re
+
+    def order(path):  # r<round>_v<version>_pmc_hbm.json, numerically
+        m = re.search(r"r(\d+)_v(\d+)_pmc_hbm", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")), key=order)
     for f in reversed(files):
         try:
             d = json.load(open(f))
@@ -223,10 +256,21 @@ def cpu_baseline(cfg, prm, n_sample):
     r = ob.phase_batch(b, prm, n_threads=cores)
     dt = time.perf_counter() - t0
     bubbles = r.phased_bubbles(b.arrays()["bubble_off"])
+    # the reference runs one thread (src/polyassembly.cpp:167-172): the same port on one core,
+    # on a smaller sample
+    n1 = max(1, min(4, n_sample))
+    c1 = dict(c)
+    c1["n_chains"] = n1
+    b1 = capi.synth_batch(**c1)
+    t1 = time.perf_counter()
+    r1 = ob.phase_batch(b1, prm, n_threads=1)
+    dt1 = time.perf_counter() - t1
     return {
         "value": bubbles / dt,
         "unit": "bubbles/s",
         "cores": cores,
+        "value_1thread": r1.phased_bubbles(b1.arrays()["bubble_off"]) / dt1,
+        "sample_1thread": f"first {n1} chains, 1 thread, {dt1:.2f} s",
         "kind": "port",
         "sample": f"first {n_sample} chains of the same workload ({bubbles} bubbles) in {dt:.2f} s wall, "
                   f"{cores} threads; CPU re-statement (oracle/oracle.cpp), not the upstream binary",
