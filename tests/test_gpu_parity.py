@@ -320,7 +320,10 @@ def test_device_result_block_matches_download():
     dev = capi.DeviceBatch(b, capi.default_params())
     dev.phase()
     res = dev.download()
-    blk = dev.result_tensor().cpu().numpy()
+    t = dev.result_tensor()
+    blk = t.cpu().numpy()
+    # the bench gathers a torch-owned device copy of the block: same content
+    np.testing.assert_array_equal(t.clone().cpu().numpy(), blk)
     status, pos_off, pos, hap = shard.decode_block(blk, b.arrays()["bubble_off"], 2)
     dev.free()
     np.testing.assert_array_equal(status, res.status)
