@@ -50,6 +50,9 @@
 #endif
 
 // tuning switches (tools/variants.sh builds and benches combinations on one box)
+#ifndef AHK_LANE_EXPAND_MAX
+#define AHK_LANE_EXPAND_MAX 8
+#endif
 #ifndef AHK_DPP_SUM
 #define AHK_DPP_SUM 1
 #endif
@@ -59,6 +62,7 @@
 
 namespace ahk {
 
+constexpr int kLaneExpandMax = AHK_LANE_EXPAND_MAX;  // P3a: bits per word up to which a lane expands its own word
 constexpr int ROLE_NONE = 0, ROLE_A = 1, ROLE_B = 2, ROLE_FA = 3, ROLE_FB = 4;
 
 // Triangle terms in 32-bit: W_PERM = INT_MAX and W_FORB = -INT_MAX act as +-infinity
@@ -152,6 +156,16 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 #endif
+}
+// inclusive prefix sum over the 64 lanes (same DPP sequence, result per lane)
+__device__ __forceinline__ int wave_scan_i(int v) {
+  v = dpp_add_step<0x111, 0xf>(v);
+  v = dpp_add_step<0x112, 0xf>(v);
+  v = dpp_add_step<0x114, 0xf>(v);
+  v = dpp_add_step<0x118, 0xf>(v);
+  v = dpp_add_step<0x142, 0xa>(v);
+  v = dpp_add_step<0x143, 0xc>(v);
+  return v;
 }
 // (for sums known to stay below 2^31: the S4a counters are at most 1023 per pair)
 __device__ __forceinline__ long long wave_sum_ll(long long v) { return (long long)wave_sum_i((int)v); }
@@ -889,31 +903,43 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             const unsigned long long nzc = rx == ROLE_A ? (oB | oFb) : rx == ROLE_B ? (oA | oFa) : rx == ROLE_FA ? oB : oA;
             cand = lvn & (nzc | Tm) & ~(Tm & low);
           }
-          // Expand the candidate words into list items, one WORD at a time with all
-          // 64 lanes (lane = column bit): neighbours of a read cluster in a few
-          // words (reads are position-sorted), so per-lane serial expansion would
-          // leave most lanes idle.  The word loop is scalar (wave-uniform).
-          unsigned long long todo = __ballot(cand != 0ull);
-          if (todo != 0ull) {
-            const int total = wave_sum_i(__popcll(cand));
+          // Item slots by an exclusive scan of the popcounts (order: lane = (row, word),
+          // then bit -- the same as a word-by-word walk).  Sparse words (the rule late
+          // in a chain: 2-3 live edges per word) are expanded by their own lane, all
+          // lanes in parallel; dense words one at a time by the whole wave, lane = bit.
+          if (__ballot(cand != 0ull) != 0ull) {
+            const int pc = __popcll(cand);
+            const int incl = wave_scan_i(pc);
             int base = 0;
-            if (lane == 0) base = atomicAdd(&s_items, total);
-            base = __builtin_amdgcn_readfirstlane(base);
+            if (lane == 63) base = atomicAdd(&s_items, incl);
+            int idx = __builtin_amdgcn_readlane(base, 63) + incl - pc;
+            unsigned long long todo = __ballot(pc > kLaneExpandMax);
+            if (pc <= kLaneExpandMax) {
+              unsigned long long mbits = cand;
+              while (mbits != 0ull) {
+                const int b = (kw << 6) + __builtin_ctzll(mbits);
+                mbits &= mbits - 1ull;
+                const unsigned int it = ((unsigned)rx << 28) | ((unsigned)role[b] << 24) | ((unsigned)x << 12) | (unsigned)b;
+                if (idx < cap) items_lds[idx] = it;
+                else items_glb[idx - cap] = it;
+                idx++;
+              }
+            }
             while (todo != 0ull) {
               const int l = __builtin_ctzll(todo);
               todo &= todo - 1ull;
               const unsigned long long w = readlane_u64(cand, l);
               const int xl = __builtin_amdgcn_readlane(x, l);
               const int rxl = __builtin_amdgcn_readlane(rx, l);
+              const int basel = __builtin_amdgcn_readlane(idx, l);
               const int kwl = l & (nwp - 1);
               if ((w >> lane) & 1ull) {
                 const int b = (kwl << 6) + lane;
-                const int idx = base + mask_rank(w);
+                const int id2 = basel + mask_rank(w);
                 const unsigned int it = ((unsigned)rxl << 28) | ((unsigned)role[b] << 24) | ((unsigned)xl << 12) | (unsigned)b;
-                if (idx < cap) items_lds[idx] = it;
-                else items_glb[idx - cap] = it;
+                if (id2 < cap) items_lds[id2] = it;
+                else items_glb[id2 - cap] = it;
               }
-              base += __popcll(w);
             }
           }
 #if defined(AHK_TIMING) && AHK_TIMING > 1
