@@ -50,6 +50,9 @@
 #endif
 
 // tuning switches (tools/variants.sh builds and benches combinations on one box)
+#ifndef AHK_P3B_SINGLE
+#define AHK_P3B_SINGLE 1
+#endif
 #ifndef AHK_LANE_EXPAND_MAX
 #define AHK_LANE_EXPAND_MAX 8
 #endif
@@ -988,6 +991,16 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
               auto seg = [&](auto nv_tag, const unsigned short* L, int cnt) {
                 constexpr int Nv = decltype(nv_tag)::value;
                 int w0 = 0;
+#if AHK_P3B_SINGLE
+                // a single member (one read opposite a clique): the most common list of all
+                if (cnt == 1) {
+                  const int w = L[0];
+                  const int ov = Wm[(unsigned)(x * n + w)], wb = Wm[(unsigned)(w * n + b)];
+                  df += icf_term(Nv, wb) - icf_term(ov, wb);
+                  dp += icp_term(Nv, wb) - icp_term(ov, wb);
+                  return;
+                }
+#endif
 #if AHK_P3B_FULL
                 // full chunks: no per-load predicate (each one costs an exec-mask branch),
                 // the four member ids come with one 8-byte LDS read
