@@ -95,3 +95,18 @@ def test_algorithmic_bytes_formula():
     A, Pn = 2 * B, 3 * 2 * B
     exp = 4 * ((R + 3) + L + R + R) + 4 * ((B + 3) + (A + 3) + Pn)
     assert b.algorithmic_input_bytes() == exp
+
+
+def test_bench_picks_newest_pmc_summary(tmp_path, monkeypatch):
+    """profiles/r<round>_v<version>_pmc_hbm.json are ordered numerically (v12 after v9)"""
+    import json
+    import bench
+
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    for tag, val in (("r01_v9", 9.0), ("r01_v12", 12.0), ("r01_v3", 3.0)):
+        (prof / f"{tag}_pmc_hbm.json").write_text(json.dumps(
+            {"config": "c3", "chains": 10000, "kernels": {"k_phase": {"hbm_bytes_fetch_x2": val}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic("c3", 10000) == 12.0
+    assert bench.pmc_traffic("c3", 123) is None
