@@ -45,6 +45,8 @@ class CChainBatch(C.Structure):
         ("rnode", i32p),
         ("read_mapq", i32p),
         ("read_name", i32p),
+        ("read_flags", u8p),
+        ("s1_order", i32p),
     ]
 
 
@@ -59,6 +61,7 @@ class CPhaseParams(C.Structure):
         ("compaction_mode", C.c_int32),
         ("device", C.c_int32),
         ("want_stages", C.c_int32),
+        ("max_slots", C.c_int32),
     ]
 
 
@@ -244,6 +247,8 @@ class ChainBatch:
         out["rnode"] = _np(c.rnode, int(out["rnode_off"][-1]) if Cn else 0, np.int32)
         out["read_mapq"] = _np(c.read_mapq, SR, np.int32)
         out["read_name"] = _np(c.read_name, SR, np.int32)
+        out["read_flags"] = _np(c.read_flags, SR, np.uint8) if c.read_flags else None
+        out["s1_order"] = _np(c.s1_order, SB, np.int32) if c.s1_order else None
         return out
 
     def algorithmic_input_bytes(self, ploidy: int = 2) -> int:
@@ -268,7 +273,8 @@ _FIELDS = [
     ("apath_off", C.c_int64, np.int64), ("apath_node", C.c_int32, np.int32), ("apath_sign", C.c_uint8, np.uint8),
     ("genotype", C.c_int32, np.int32), ("node_off", C.c_int64, np.int64), ("node_id", C.c_int32, np.int32),
     ("read_off", C.c_int64, np.int64), ("rnode_off", C.c_int64, np.int64), ("rnode", C.c_int32, np.int32),
-    ("read_mapq", C.c_int32, np.int32), ("read_name", C.c_int32, np.int32),
+    ("read_mapq", C.c_int32, np.int32), ("read_name", C.c_int32, np.int32), ("read_flags", C.c_uint8, np.uint8),
+    ("s1_order", C.c_int32, np.int32),
 ]
 
 # BASELINE.json configs -> generator specs; seed = 0xA450CA00 + config number

@@ -466,7 +466,7 @@ int read_gaf(const char* path, GafTable* out) {
 }  // namespace
 
 // Text dump of everything the ingest derived, in the line format of
-// oracle/ref_harness.cpp (CHAIN / BUBBLE / ALLELE / ALN / ORDER), so the two can
+// oracle/ref_harness.cpp (CHAIN / BUBBLE / ALLELE / ALN / S1ORDER / ORDER), so the two can
 // be compared byte for byte; also the source of <o>-bubbleinfo.txt.
 extern "C" int ahsoka_ingest_dump(const char* gfa_path, const char* gaf_path, const char* out_path) {
   if (!gfa_path || !out_path) return AHSOKA_E_ARG;
@@ -520,11 +520,19 @@ extern "C" int ahsoka_ingest_dump(const char* gfa_path, const char* gaf_path, co
         const size_t li = (size_t)lc.first;
         const float scaled = gaf.identity[li] * 100;
         const std::string nm(gaf.name(li));
-        std::fprintf(f, "ALN %d %s %d %d %zu", kv.first, nm.c_str(), (int)scaled, lc.second,
-                     (size_t)(gaf.node_off[li + 1] - gaf.node_off[li]));
+        std::fprintf(f, "ALN %d %s %d %d %d %zu", kv.first, nm.c_str(), (int)scaled, (int)ahk::ref_gt90_flag(gaf.identity[li]),
+                     lc.second, (size_t)(gaf.node_off[li + 1] - gaf.node_off[li]));
         for (uint64_t e = gaf.node_off[li]; e < gaf.node_off[li + 1]; e++) std::fprintf(f, " %d", gaf.nodes[e]);
         std::fprintf(f, "\n");
       }
+    // the order in which S1 walks each chain's bubbles (src/alignmentstoreadset.cpp:76,90)
+    for (auto& oc : order) {
+      std::vector<int32_t> s1;
+      ahk::ref_s1_order((int)g.chains[(size_t)oc.second].bubbles.size(), &s1);
+      std::fprintf(f, "S1ORDER %d", oc.second);
+      for (int32_t k : s1) std::fprintf(f, " %d", k);
+      std::fprintf(f, "\n");
+    }
     std::fprintf(f, "ORDER");
     for (auto& oc : order) std::fprintf(f, " %d", oc.second);
     std::fprintf(f, "\n");
@@ -624,6 +632,9 @@ extern "C" int ahsoka_ingest(const char* gfa_path, const char* gaf_path, ahsoka_
         hb->allele_off.push_back((int64_t)hb->apath_off.size() - 1);
       }
       hb->bubble_off.push_back((int64_t)hb->allele_off.size() - 1);
+      // S1 visits the bubbles in the iteration order of the chain's unordered_map
+      // (src/alignmentstoreadset.cpp:76,90); bubble ids are 0..B-1 in ch.bubbles order
+      ahk::ref_s1_order((int)ch.bubbles.size(), &hb->s1_order);
       hb->node_off.push_back((int64_t)hb->node_id.size());
       std::unordered_map<std::string_view, int> name_id;
       name_id.reserve(lines_of_chain[(size_t)ch.id].size() * 2);
@@ -635,6 +646,7 @@ extern "C" int ahsoka_ingest(const char* gfa_path, const char* gaf_path, ahsoka_
         hb->rnode_off.push_back((int64_t)hb->rnode.size());
         const float scaled = gaf.identity[li] * 100;  // float multiply, then the implicit float->int of the Read ctor
         hb->read_mapq.push_back((int32_t)scaled);
+        hb->read_flags.push_back(ahk::ref_gt90_flag(gaf.identity[li]));  // :245, on the float
         auto ins = name_id.emplace(gaf.name(li), (int)name_id.size());
         hb->read_name.push_back(ins.first->second);
       }

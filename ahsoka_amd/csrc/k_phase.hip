@@ -506,7 +506,9 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     }
     __syncthreads();
 
-    if (lds.stop_after == 1) continue;  // profiling aid only (results invalid)
+#ifdef AHK_DIAG
+    if (lds.stop_after == 1) continue;  // diagnostic build only (results invalid)
+#endif
 
     // ================= S5 init: induced costs of every live edge ===========
     // icf(ab) = max(w_ab,0) + sum_w min(w_aw,w_bw)+ ; icp likewise.  One wave per
@@ -594,7 +596,9 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     if (tid < 4) s_cnt[tid] = 0;
     if (tid == 0) { s_nd = 0; s_items = 0; }
     __syncthreads();
-    if (lds.stop_after == 2) continue;  // profiling aid only (results invalid)
+#ifdef AHK_DIAG
+    if (lds.stop_after == 2) continue;
+#endif
 
     // ================= S5 main loop ========================================
     long long iters = 0;
@@ -1200,7 +1204,9 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       for (int b = 0; b < 8; b++) printf("M<=%d: iters=%lld cyc/iter=%lld | T<=%d: iters=%lld cyc/iter=%lld\n", 32 << b, hM[b], hM[b] ? hMc[b] / hM[b] : 0, 2 << b, hT[b], hT[b] ? hTc[b] / hT[b] : 0);
     }
 #endif
+#ifdef AHK_DIAG
     if (lds.stop_after == 3) continue;
+#endif
 
     // ---- clusters: ordered by smallest member ------------------------------
     // (bestF is free now: reuse as scratch)

@@ -35,18 +35,19 @@ __device__ __forceinline__ bool tba_test(const unsigned int* tba, int k) {
 // is outside the alignment loop in the reference (:98-106, :214-222), so the
 // lowest allele any alignment of that name matches wins, and among those the
 // earliest alignment created the Read (its identity becomes the Read's mapq).
-// mapq_gt: only alignments with read_mapq > mapq_gt count (-1 = all).  S2 adds a
-// variant to an EXISTING read only if `alignment.id*100 > 90` (:245); the variant
-// that creates the read is exempt.
+// need_gt90: only alignments whose `alignment.id*100 > 90` holds count -- a FLOAT
+// compare in the reference (:245), carried as bit 0 of read_flags.  S2 adds a
+// variant to an EXISTING read only from such alignments; the variant that
+// creates the read is exempt.
 __device__ __forceinline__ int merged_allele(const signed char* __restrict__ v, long long R, int k,
                                              const long long* __restrict__ name_off,
                                              const int* __restrict__ name_aln, int g, int* creator,
-                                             const int* __restrict__ mapq = nullptr, int mapq_gt = -1) {
+                                             const unsigned char* __restrict__ flags = nullptr, bool need_gt90 = false) {
   int best_a = 127, best_r = -1;
   for (long long ai = name_off[g]; ai < name_off[g + 1]; ai++) {
     int r = name_aln[ai];
     int a = v[(long long)k * R + r];
-    if (mapq_gt >= 0 && mapq[r] <= mapq_gt) continue;
+    if (need_gt90 && !(flags[r] & 1)) continue;
     if (a >= 0 && a < best_a) {
       best_a = a;
       best_r = r;
@@ -160,15 +161,20 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
   const int* name_aln = db.name_aln + m.r0;
 
   // ---- phase B: S1b filter and S1c boundary sets ---------------------------
+  // S1 walks the bubbles in the iteration order of the reference's unordered_map
+  // (:76,:90): the first hit IN THAT ORDER creates the Read and fixes its mapq.
+  const int* s1 = db.s1_order + m.b0;
   for (int g = tid; g < G; g += kBlock) {
-    int nvar = 0, first = -1, last = -1, mapq = -1;
-    for (int k = 0; k < B; k++) {
+    int nvar = 0, first = B, last = -1, mapq = -1;
+    for (int kk = 0; kk < B; kk++) {
+      const int k = s1[kk];
       int cr;
       int a = merged_allele(vfull, R, k, name_off, name_aln, g, &cr);
       if (a < 0) continue;
+      if (nvar == 0) mapq = db.read_mapq[m.r0 + cr];
       nvar++;
-      if (first < 0) { first = k; mapq = db.read_mapq[m.r0 + cr]; }
-      last = k;
+      first = k < first ? k : first;
+      last = k > last ? k : last;
     }
     if (nvar > 0) {
       atomicMax(&s_maxpos, last);
@@ -203,14 +209,14 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
   __syncthreads();
 
   // ---- phase C: S2 variants restricted to to_be_added, S2b filter ----------
-  const int* mq = db.read_mapq + m.r0;
+  const unsigned char* fl = db.read_flags + m.r0;
   for (int g = tid; g < G; g += kBlock) {
     int nvar = 0, first = -1, afirst = 0, rcre = 0, mapq = -1;
     for (int k = 0; k < B; k++) {
       if (!tba_test(tba, k)) continue;
       int cr;
       // the first hit creates the Read (any identity); later positions need > 90
-      int a = merged_allele(vpart, R, k, name_off, name_aln, g, &cr, mq, first < 0 ? -1 : 90);
+      int a = merged_allele(vpart, R, k, name_off, name_aln, g, &cr, fl, first >= 0);
       if (a < 0) continue;
       nvar++;
       if (first < 0) { first = k; afirst = a; rcre = cr; mapq = db.read_mapq[m.r0 + cr]; }
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
       for (int k = first; k < B; k++) {
         if (!tba_test(tba, k)) continue;
         int cr;
-        if (merged_allele(vpart, R, k, name_off, name_aln, g, &cr, mq, k == first ? -1 : 90) >= 0)
+        if (merged_allele(vpart, R, k, name_off, name_aln, g, &cr, fl, k != first) >= 0)
           atomicOr(&posm[k >> 5], 1u << (k & 31));
       }
     }
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
         if (!((posm[k >> 5] >> (k & 31)) & 1u)) continue;
         j = cidx[k];
         int cr;
-        a = k < gfirst ? -1 : merged_allele(vpart, R, k, name_off, name_aln, g, &cr, mq, k == gfirst ? -1 : 90);
+        a = k < gfirst ? -1 : merged_allele(vpart, R, k, name_off, name_aln, g, &cr, fl, k != gfirst);
       }
       const int wj = (k < B) ? (j >> 6) : Wp;  // k == B flushes the tail
       while (curw < wj) {

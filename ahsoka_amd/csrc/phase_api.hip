@@ -15,10 +15,12 @@
 #include <new>
 #include <numeric>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "detmath.h"
 #include "gnusort.h"
+#include "host_batch.h"
 #include "phase_kernels.h"
 #include "../../include/ahsoka_phase.h"
 
@@ -42,21 +44,36 @@ struct DevBuf {
 
 }  // namespace
 
+// One size class of k_phase: chains whose final readset has at most nmax reads share
+// a pool of `slots` workgroups (one slot of HBM working state each) and one launch of
+// the persistent grid with LDS sized for nmax.  A batch of similar chains (configs
+// 1-4) is one class; the power-law config 5 gets up to four, so that its few large
+// chains do not dictate the footprint (and LDS occupancy) of the many small ones.
+struct PhaseClass {
+  int nmax = 0, slots = 0, count = 0, Pmax = 1;
+  PhaseLds pl{};
+  SlotWorkspace ws{};
+  int* queue = nullptr;  // device: this class's chains, most expensive first
+  int* qhead = nullptr;  // device: atomic cursor
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+};
+
 struct ahsoka_device_batch {
   ahsoka_phase_params prm;
   int C = 0;
   int device = 0;
   std::vector<ChainMeta> meta;
   std::vector<void*> allocs;
+  std::vector<void*> ws_allocs;  // slot workspaces (released as a whole if their allocation fails)
   DeviceBatch db;
-  SlotWorkspace ws;
   ReadsetLds rl;
-  PhaseLds pl;
-  int* queue = nullptr;
-  int* qhead = nullptr;
+  std::vector<PhaseClass> classes;
+  int* qheads = nullptr;
   int maxG = 1, maxB = 1, n_cu = 1;
   size_t lds_per_block = 0;
   bool ws_ready = false;
+  int stop_after = 0;
   int* packed = nullptr;  // [status | npos | pos | hap_allele] for ahsoka_batch_result_device
   int slots = 0;
   hipStream_t stream = nullptr;
@@ -98,6 +115,7 @@ extern "C" void ahsoka_default_params(ahsoka_phase_params* prm) {
   prm->compaction_mode = 0;
   prm->device = 0;
   prm->want_stages = 0;
+  prm->max_slots = 0;
 }
 
 extern "C" int ahsoka_abi_version(void) { return AHSOKA_ABI_VERSION; }
@@ -154,6 +172,15 @@ static int validate_batch(const ahsoka_chain_batch* in) {
         if (in->rnode[e] < -1 || in->rnode[e] >= N) return AHSOKA_E_ARG;
       if (in->read_name[r] < 0 || in->read_name[r] >= in->read_off[c + 1] - in->read_off[c]) return AHSOKA_E_ARG;
     }
+    if (in->s1_order) {  // must be a permutation of the chain's bubble ids
+      const long long b0 = in->bubble_off[c], B = in->bubble_off[c + 1] - b0;
+      std::vector<unsigned char> seen((size_t)B, 0);
+      for (long long k = 0; k < B; k++) {
+        const int v = in->s1_order[b0 + k];
+        if (v < 0 || v >= B || seen[(size_t)v]) return AHSOKA_E_ARG;
+        seen[(size_t)v] = 1;
+      }
+    }
   }
   return AHSOKA_OK;
 }
@@ -161,7 +188,7 @@ static int validate_batch(const ahsoka_chain_batch* in) {
 extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_phase_params* prm,
                                    ahsoka_device_batch** handle) {
   if (!in || !prm || !handle) return AHSOKA_E_ARG;
-  if (prm->ploidy < 2 || prm->ploidy > kMaxPloidy || prm->min_overlap < 0) return AHSOKA_E_ARG;
+  if (prm->ploidy < 2 || prm->ploidy > kMaxPloidy || prm->min_overlap < 0 || prm->max_slots < 0) return AHSOKA_E_ARG;
   if (int e = validate_batch(in)) return e;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return AHSOKA_E_NODEVICE;
@@ -174,12 +201,15 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   h->device = prm->device;
   const int C = h->C = in->n_chains;
   std::memset(&h->db, 0, sizeof(h->db));
-  std::memset(&h->ws, 0, sizeof(h->ws));
   int rc = AHSOKA_OK;
   auto fail = [&](int code) {
     ahsoka_batch_free(h);
     return code;
   };
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, prm->device) != hipSuccess) return fail(AHSOKA_E_NODEVICE);
+  h->n_cu = prop.multiProcessorCount;
+  h->lds_per_block = (size_t)prop.sharedMemPerBlock;
 
   // ---- per-chain metadata, name CSR, limits --------------------------------
   h->meta.resize(C);
@@ -212,6 +242,10 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
       for (int r = 0; r < m.R; r++) name_aln[(size_t)m.r0 + cur[in->read_name[m.r0 + r]]++] = r;
     }
     bool unsupported = m.B > kMaxBubbles || m.N > kMaxNodes || G > kMaxNames || m.R > 131071;
+    // a chain whose k_readset working set does not fit this device's LDS is reported
+    // per chain, like the compiled-in limits, instead of failing the whole batch
+    if (!unsupported && readset_lds_bytes(ReadsetLds{(m.N + 63) / 64, std::max(G, 1), std::max(m.B, 1)}) > h->lds_per_block)
+      unsupported = true;
     for (long long g = m.b0; g < m.b0 + m.B; g++) {
       const int na = (int)(in->allele_off[g + 1] - in->allele_off[g]);
       if (na > kMaxAlleles) unsupported = true;
@@ -269,6 +303,27 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   if ((rc = h->dupload(&db.rnode_off, (const long long*)in->rnode_off, (size_t)SR + 1))) return fail(rc);
   if ((rc = h->dupload(&db.rnode, (const int*)in->rnode, (size_t)SL))) return fail(rc);
   if ((rc = h->dupload(&db.read_mapq, (const int*)in->read_mapq, (size_t)SR))) return fail(rc);
+  if (in->read_flags) {
+    if ((rc = h->dupload(&db.read_flags, (const unsigned char*)in->read_flags, (size_t)SR))) return fail(rc);
+  } else {  // documented fallback: the guard of :245 on the truncated identity
+    std::vector<unsigned char> fl((size_t)SR);
+    for (long long r = 0; r < SR; r++) fl[(size_t)r] = in->read_mapq[r] > 90 ? 1 : 0;
+    if ((rc = h->dupload(&db.read_flags, (const unsigned char*)fl.data(), (size_t)SR))) return fail(rc);
+  }
+  if (in->s1_order) {
+    if ((rc = h->dupload(&db.s1_order, (const int*)in->s1_order, (size_t)SB))) return fail(rc);
+  } else {  // the order the reference's own map construction gives (host_batch.h)
+    std::vector<int32_t> ord;
+    ord.reserve((size_t)SB);
+    std::vector<std::vector<int32_t>> memo;  // by B: chains of equal size share the order
+    for (int c = 0; c < C; c++) {
+      const size_t B = (size_t)h->meta[c].B;
+      if (memo.size() <= B) memo.resize(B + 1);
+      if (B > 0 && memo[B].empty()) ahk::ref_s1_order((int)B, &memo[B]);
+      ord.insert(ord.end(), memo[B].begin(), memo[B].end());
+    }
+    if ((rc = h->dupload(&db.s1_order, (const int*)ord.data(), (size_t)SB))) return fail(rc);
+  }
   if ((rc = h->dupload(&db.meta, h->meta.data(), (size_t)C))) return fail(rc);
   if ((rc = h->dupload(&db.name_off, name_off.data(), name_off.size()))) return fail(rc);
   if ((rc = h->dupload(&db.name_aln, name_aln.data(), name_aln.size()))) return fail(rc);
@@ -309,29 +364,12 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   h->rl.maxB = maxB;
   h->maxG = maxG;
   h->maxB = maxB;
-  h->pl.nmax = 0;  // the slot workspace is sized after the first k_readset (see alloc_slots)
-  h->pl.stop_after = 0;
-  if (const char* sa = std::getenv("AHSOKA_STOP_AFTER")) h->pl.stop_after = std::atoi(sa);  // profiling aid
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, prm->device) != hipSuccess) return fail(AHSOKA_E_NODEVICE);
-  h->n_cu = prop.multiProcessorCount;
-  h->lds_per_block = (size_t)prop.sharedMemPerBlock;
-  if (readset_lds_bytes(h->rl) > h->lds_per_block) return fail(AHSOKA_E_UNSUPPORTED);
-
-  // work queue: largest chains first (the reference orders chains by size too,
-  // src/polyassembly.cpp:136-140; here it balances the persistent grid)
-  std::vector<int> order(C);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    const double ca = (double)h->meta[a].G * h->meta[a].G * h->meta[a].B, cb = (double)h->meta[b].G * h->meta[b].G * h->meta[b].B;
-    return ca > cb;
-  });
-  {
-    const int* q = nullptr;
-    if ((rc = h->dupload(&q, order.data(), (size_t)C))) return fail(rc);
-    h->queue = const_cast<int*>(q);
-  }
-  if ((rc = h->dalloc(&h->qhead, 1))) return fail(rc);
+  // (the k_phase queues and slot workspaces are built after the first k_readset, when
+  // the sizes of the final readsets are known: see build_classes)
+#ifdef AHK_DIAG
+  if (const char* sa = std::getenv("AHSOKA_STOP_AFTER")) h->stop_after = std::atoi(sa);  // diagnostic builds only
+#endif
+  if (readset_lds_bytes(h->rl) > h->lds_per_block) return fail(AHSOKA_E_UNSUPPORTED);  // (cannot happen: such chains were flagged)
   if (hipStreamCreate(&h->stream) != hipSuccess) return fail(AHSOKA_E_HIP);
   for (int i = 0; i < 3; i++)
     if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(AHSOKA_E_HIP);
@@ -339,56 +377,159 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   return AHSOKA_OK;
 }
 
-// The per-slot state of k_phase (W, IC, bitmaps: ~24 B per read pair) is sized
-// by the largest FINAL readset, which is only known after k_readset has run
-// (reads are filtered by identity and variant count: ~600 of 1000 survive at
-// config 3).  Sizing by it instead of by the number of read names shrinks the
-// footprint of the 1024 chains in flight 2-3x (fewer TLB misses, better L2 reuse).
-static int alloc_slots(ahsoka_device_batch* h) {
-  std::vector<int> nfin((size_t)h->C);
-  if (hipMemcpy(nfin.data(), h->db.nfin, (size_t)h->C * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return AHSOKA_E_HIP;
-  int nact = 8;
-  for (int v : nfin) nact = std::max(nact, v);
-  h->pl.nmax = (std::min(nact, kMaxReads) + 63) & ~63;
-  if (phase_lds_bytes(h->pl) > h->lds_per_block) return AHSOKA_E_UNSUPPORTED;
-  int per_cu_cap = 5;
-  if (const char* e = std::getenv("AHSOKA_WG_PER_CU")) per_cu_cap = std::max(1, std::atoi(e));  // tuning aid
-  const int per_cu = std::min(phase_max_blocks_per_cu(h->pl), per_cu_cap);
-  int slots = std::min(h->C, h->n_cu * per_cu);
-  if (slots < 1) slots = 1;
-  SlotWorkspace& ws = h->ws;
-  ws.nmax = h->pl.nmax;
-  ws.Pmax = h->maxB;
-  long long T = 1;
-  for (int i = 0; i < h->prm.ploidy; i++) T *= 2 * h->prm.ploidy;
-  ws.Tmax = T;
-  {
+// The per-slot state of k_phase (W, IC, bitmaps: ~24 B per read pair) is sized by
+// the FINAL readsets, which are only known after k_readset has run (reads are
+// filtered by identity and variant count: ~600 of 1000 survive at config 3).
+// Chains are binned into size classes by their final read count n: the largest
+// class holds chains up to top = max n (rounded up to 64), the next ones up to
+// top/2, top/4, top/8.  Every non-empty class gets its own pool of slots, its own
+// work queue (most expensive chain first: the reference orders chains by size too,
+// src/polyassembly.cpp:136-140; here it balances the persistent grid) and its own
+// launch of k_phase with LDS sized for the class -- all launches run concurrently.
+static size_t class_slot_bytes(const PhaseClass& pc, long long Tmax) {
+  const double nn = (double)pc.nmax * pc.nmax;
+  const double words = (double)pc.nmax * ((pc.nmax + 63) / 64);
+  return (size_t)(nn * (4 + 16 + 4) + words * 16 + (double)pc.nmax * (16 + 16) + (double)pc.Pmax * (4 + 8 * (4 + 8 + 4 + 4) + 4) +
+                  (double)pc.Pmax * (double)Tmax * (4 + 8 + 2) + 4096);
+}
+
+static void free_classes(ahsoka_device_batch* h) {
+  for (void* p : h->ws_allocs) (void)hipFree(p);
+  h->ws_allocs.clear();
+  for (PhaseClass& pc : h->classes) {
+    if (pc.done) (void)hipEventDestroy(pc.done);
+    if (pc.stream) (void)hipStreamDestroy(pc.stream);
+  }
+  h->classes.clear();
+  h->qheads = nullptr;
+  h->slots = 0;
+}
+
+static int build_classes(ahsoka_device_batch* h) {
+  const int C = h->C;
+  std::vector<int> nfin((size_t)C), status((size_t)C);
+  if (hipMemcpy(nfin.data(), h->db.nfin, (size_t)C * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return AHSOKA_E_HIP;
+  if (hipMemcpy(status.data(), h->db.status, (size_t)C * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return AHSOKA_E_HIP;
+  // largest readset whose per-read LDS arrays fit a workgroup of this device
+  int ncap = 64;
+  for (int v = 64; v <= ((kMaxReads + 63) & ~63); v += 64) {
+    PhaseLds t{v, 0};
+    if (phase_lds_bytes(t) <= h->lds_per_block) ncap = v;
+  }
+  bool demoted = false;
+  int top = 0;
+  for (int c = 0; c < C; c++) {
+    if (status[c] != AHSOKA_ST_PHASED) continue;
+    if (nfin[c] > ncap) {  // per chain, like the compiled-in limits
+      status[c] = AHSOKA_ST_UNSUPPORTED;
+      demoted = true;
+      continue;
+    }
+    top = std::max(top, nfin[c]);
+  }
+  if (demoted && hipMemcpy(h->db.status, status.data(), (size_t)C * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return AHSOKA_E_HIP;
+  if (top == 0) {  // nothing to phase: no class, no launch
+    h->ws_ready = true;
+    return AHSOKA_OK;
+  }
+  std::vector<int> caps;
+  for (int i = 0; i < 4; i++) {
+    const int v = std::max(64, ((((top + (1 << i) - 1) >> i)) + 63) & ~63);
+    if (!caps.empty() && v >= caps.back()) break;
+    caps.push_back(v);
+  }
+  auto class_of = [&](int n) {
+    int k = 0;
+    while (k + 1 < (int)caps.size() && n <= caps[k + 1]) k++;
+    return k;
+  };
+  std::vector<std::vector<int>> members(caps.size());
+  for (int c = 0; c < C; c++)
+    if (status[c] == AHSOKA_ST_PHASED) members[(size_t)class_of(nfin[c])].push_back(c);
+  long long Tmax = 1;
+  for (int i = 0; i < h->prm.ploidy; i++) Tmax *= 2 * h->prm.ploidy;
+  int per_cu_cap = 5;  // launch bounds of k_phase: five workgroups of four waves per CU
+#ifdef AHK_DIAG
+  if (const char* e = std::getenv("AHSOKA_WG_PER_CU")) per_cu_cap = std::max(1, std::atoi(e));  // diagnostic builds only
+#endif
+  for (size_t k = 0; k < caps.size(); k++) {
+    if (members[k].empty()) continue;
+    PhaseClass pc;
+    pc.nmax = caps[k];
+    pc.count = (int)members[k].size();
+    pc.pl.nmax = pc.nmax;
+    pc.pl.stop_after = h->stop_after;
+    for (int c : members[k]) pc.Pmax = std::max(pc.Pmax, h->meta[(size_t)c].B);
+    const int per_cu = std::min(phase_max_blocks_per_cu(pc.pl), per_cu_cap);
+    pc.slots = std::max(1, std::min(pc.count, h->n_cu * per_cu));
+    if (h->prm.max_slots > 0) pc.slots = std::min(pc.slots, h->prm.max_slots);
+    h->classes.push_back(pc);
+  }
+  {  // fit the slot pools into 60 % of the free HBM: shrink the largest pool first
     size_t freeb = 0, totalb = 0;
     if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) return AHSOKA_E_HIP;
-    const double per_slot = (double)ws.nmax * ws.nmax * 24.2 + (double)ws.Pmax * ws.Tmax * 14.0 + 1e5;
-    const long long fit = (long long)((double)freeb * 0.6 / per_slot);
-    if (fit < 1) return AHSOKA_E_NOMEM;
-    if (slots > fit) slots = (int)fit;
+    const double budget = (double)freeb * 0.6;
+    for (;;) {
+      double sum = 0;
+      size_t big = 0;
+      double bigb = -1;
+      for (size_t k = 0; k < h->classes.size(); k++) {
+        const double b = (double)class_slot_bytes(h->classes[k], Tmax) * h->classes[k].slots;
+        sum += b;
+        if (h->classes[k].slots > 1 && b > bigb) { bigb = b; big = k; }
+      }
+      if (sum <= budget) break;
+      if (bigb < 0) { free_classes(h); return AHSOKA_E_NOMEM; }
+      h->classes[big].slots = std::max(1, h->classes[big].slots * 3 / 4);
+    }
   }
-  h->slots = slots;
-  const size_t S = (size_t)slots;
-  int rc;
-  if ((rc = h->dalloc(&ws.W, S * ws.nmax * ws.nmax))) return rc;
-  if ((rc = h->dalloc(&ws.IC, S * ws.nmax * ws.nmax))) return rc;
-  if ((rc = h->dalloc(&ws.live, S * ws.nmax * ((ws.nmax + 63) / 64)))) return rc;
-  if ((rc = h->dalloc(&ws.nz, S * ws.nmax * ((ws.nmax + 63) / 64)))) return rc;
-  if ((rc = h->dalloc(&ws.items, S * ws.nmax * ws.nmax))) return rc;
-  if ((rc = h->dalloc(&ws.rates, S * 2 * ws.nmax))) return rc;
-  if ((rc = h->dalloc(&ws.tp_k, S * ws.Pmax))) return rc;
-  if ((rc = h->dalloc(&ws.tp_gcid, S * ws.Pmax * 8))) return rc;
-  if ((rc = h->dalloc(&ws.tp_cov, S * ws.Pmax * 8))) return rc;
-  if ((rc = h->dalloc(&ws.tp_cons, S * ws.Pmax * 8))) return rc;
-  if ((rc = h->dalloc(&ws.tp_consmap, S * ws.Pmax * 8))) return rc;
-  if ((rc = h->dalloc(&ws.tp_ntup, S * ws.Pmax))) return rc;
-  if ((rc = h->dalloc(&ws.tp_tuples, S * ws.Pmax * ws.Tmax))) return rc;
-  if ((rc = h->dalloc(&ws.tp_score, S * ws.Pmax * ws.Tmax))) return rc;
-  if ((rc = h->dalloc(&ws.tp_pred, S * ws.Pmax * ws.Tmax))) return rc;
-  if ((rc = h->dalloc(&ws.sortbuf, S * 4 * ws.nmax))) return rc;
+  auto wsalloc = [&](auto** out, size_t count) -> int {
+    using T = std::remove_pointer_t<std::remove_pointer_t<decltype(out)>>;
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (hipMalloc(&p, bytes) != hipSuccess) return AHSOKA_E_NOMEM;
+    h->ws_allocs.push_back(p);
+    h->device_bytes += bytes;
+    *out = (T*)p;
+    return AHSOKA_OK;
+  };
+  int rc = AHSOKA_OK;
+  if ((rc = wsalloc(&h->qheads, h->classes.size()))) { free_classes(h); return rc; }
+  size_t ki = 0, mi = 0;
+  for (PhaseClass& pc : h->classes) {
+    while (members[mi].empty()) mi++;
+    std::vector<int>& q = members[mi++];
+    std::stable_sort(q.begin(), q.end(), [&](int a, int b) {
+      const double ca = (double)nfin[a] * nfin[a] * h->meta[(size_t)a].B, cb = (double)nfin[b] * nfin[b] * h->meta[(size_t)b].B;
+      return ca > cb;
+    });
+    pc.qhead = h->qheads + ki++;
+    SlotWorkspace& ws = pc.ws;
+    ws.nmax = pc.nmax;
+    ws.Pmax = pc.Pmax;
+    ws.Tmax = Tmax;
+    const size_t S = (size_t)pc.slots, nn = (size_t)ws.nmax * ws.nmax, words = (size_t)ws.nmax * ((ws.nmax + 63) / 64);
+    if ((rc = wsalloc(&pc.queue, q.size())) || (rc = wsalloc(&ws.W, S * nn)) || (rc = wsalloc(&ws.IC, S * nn)) ||
+        (rc = wsalloc(&ws.live, S * words)) || (rc = wsalloc(&ws.nz, S * words)) || (rc = wsalloc(&ws.items, S * nn)) ||
+        (rc = wsalloc(&ws.rates, S * 2 * ws.nmax)) || (rc = wsalloc(&ws.tp_k, S * ws.Pmax)) ||
+        (rc = wsalloc(&ws.tp_gcid, S * ws.Pmax * 8)) || (rc = wsalloc(&ws.tp_cov, S * ws.Pmax * 8)) ||
+        (rc = wsalloc(&ws.tp_cons, S * ws.Pmax * 8)) || (rc = wsalloc(&ws.tp_consmap, S * ws.Pmax * 8)) ||
+        (rc = wsalloc(&ws.tp_ntup, S * ws.Pmax)) || (rc = wsalloc(&ws.tp_tuples, S * ws.Pmax * ws.Tmax)) ||
+        (rc = wsalloc(&ws.tp_score, S * ws.Pmax * ws.Tmax)) || (rc = wsalloc(&ws.tp_pred, S * ws.Pmax * ws.Tmax)) ||
+        (rc = wsalloc(&ws.sortbuf, S * 4 * ws.nmax))) {
+      free_classes(h);
+      return rc;
+    }
+    if (hipMemcpy(pc.queue, q.data(), q.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { free_classes(h); return AHSOKA_E_HIP; }
+    h->slots += pc.slots;
+  }
+  if (h->classes.size() > 1)
+    for (PhaseClass& pc : h->classes)
+      if (hipStreamCreateWithFlags(&pc.stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&pc.done, hipEventDisableTiming) != hipSuccess) {
+        free_classes(h);
+        return AHSOKA_E_HIP;
+      }
   h->ws_ready = true;
   return AHSOKA_OK;
 }
@@ -398,17 +539,30 @@ extern "C" int ahsoka_phase_device(ahsoka_device_batch* h) {
   HIP_TRY(hipSetDevice(h->device));
   if (h->C == 0) return AHSOKA_OK;
   auto t0 = std::chrono::steady_clock::now();
-  HIP_TRY(hipMemsetAsync(h->qhead, 0, sizeof(int), h->stream));
   HIP_TRY(hipEventRecord(h->ev[0], h->stream));
   launch_readset(h->db, h->C, h->rl, h->stream);
   HIP_TRY(hipGetLastError());
-  if (!h->ws_ready) {  // first call only: size the slot workspace by the real readsets
+  if (!h->ws_ready) {  // first call only: size classes and slot pools from the real readsets
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (int rc = alloc_slots(h)) return rc;
+    if (int rc = build_classes(h)) return rc;
   }
+  if (!h->classes.empty()) HIP_TRY(hipMemsetAsync(h->qheads, 0, h->classes.size() * sizeof(int), h->stream));
   HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-  launch_phase(h->db, h->ws, h->pl, h->queue, h->C, h->qhead, h->slots, h->stream);
-  HIP_TRY(hipGetLastError());
+  if (h->classes.size() == 1) {
+    PhaseClass& pc = h->classes[0];
+    launch_phase(h->db, pc.ws, pc.pl, pc.queue, pc.count, pc.qhead, pc.slots, h->stream);
+    HIP_TRY(hipGetLastError());
+  } else {
+    // one launch per size class, each on its own stream: they share the CUs, the
+    // class of the largest chains first in line
+    for (PhaseClass& pc : h->classes) {
+      HIP_TRY(hipStreamWaitEvent(pc.stream, h->ev[1], 0));
+      launch_phase(h->db, pc.ws, pc.pl, pc.queue, pc.count, pc.qhead, pc.slots, pc.stream);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(pc.done, pc.stream));
+      HIP_TRY(hipStreamWaitEvent(h->stream, pc.done, 0));
+    }
+  }
   HIP_TRY(hipEventRecord(h->ev[2], h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipEventElapsedTime(&h->k_ms[0], h->ev[0], h->ev[1]));
@@ -547,6 +701,7 @@ extern "C" int ahsoka_batch_download(ahsoka_device_batch* h, ahsoka_phase_result
 extern "C" void ahsoka_batch_free(ahsoka_device_batch* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  free_classes(h);
   for (void* p : h->allocs) (void)hipFree(p);
   for (int i = 0; i < 3; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);

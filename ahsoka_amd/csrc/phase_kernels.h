@@ -48,6 +48,8 @@ struct DeviceBatch {
   const long long* rnode_off;
   const int* rnode;
   const int* read_mapq;
+  const unsigned char* read_flags;  // [SR] bit0: float(id)*100 > 90 (reference :245)
+  const int* s1_order;              // [SB] per chain: bubble ids in S1 visiting order (reference :76,90)
   // derived on host
   const ChainMeta* meta;
   const long long* name_off;  // [sum(G)+C] per-chain CSR
@@ -110,7 +112,7 @@ struct ReadsetLds {
 };
 struct PhaseLds {
   int nmax;        // capacity of the per-read LDS arrays
-  int stop_after;  // 0 = run everything; 2/3: profiling aid, stop after S5 init / S5 loop
+  int stop_after;  // diagnostic builds (-DAHK_DIAG) only: 1/2/3 = stop after S4 / S5 init / S5 loop
 };
 size_t readset_lds_bytes(const ReadsetLds& l);
 void launch_readset(const DeviceBatch& db, int C, const ReadsetLds& l, hipStream_t stream);

@@ -14,6 +14,7 @@
 // index), so a rank can generate exactly its shard of the global workload.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -148,13 +149,20 @@ extern "C" int ahsoka_synth_batch(const ahsoka_synth_spec* sp, ahsoka_chain_batc
         hb->allele_off.push_back((int64_t)hb->apath_off.size() - 1);
       }
       hb->bubble_off.push_back((int64_t)hb->allele_off.size() - 1);
+      ahk::ref_s1_order(ch.B, &hb->s1_order);
       for (int x = 0; x < 3 * ch.B + 1; x++) hb->node_id.push_back((int32_t)(base + x + 1));
       hb->node_off.push_back((int64_t)hb->node_id.size());
       base += 3 * (int64_t)ch.B + 1;
       for (int r = 0; r < ch.R; r++) {
         for (int nd : ch.reads[r]) hb->rnode.push_back(nd);
         hb->rnode_off.push_back((int64_t)hb->rnode.size());
-        hb->read_mapq.push_back(ch.idnum[r] / 10);  // (int)(stof("0.NNN")*100), SURVEY.md D
+        // what the reference derives from the token "id:f:0.NNN" the text form carries:
+        // std::stof, then float*100 truncated (:117) resp. compared with 90 (:245)
+        char tok[16];
+        std::snprintf(tok, sizeof tok, "0.%03d", ch.idnum[r]);
+        const float ident = std::strtof(tok, nullptr);
+        hb->read_mapq.push_back((int32_t)(ident * 100));
+        hb->read_flags.push_back(ahk::ref_gt90_flag(ident));
         hb->read_name.push_back(r);
       }
       hb->read_off.push_back((int64_t)hb->read_mapq.size());

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AHSOKA_ABI_VERSION 1
+#define AHSOKA_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------- */
 #define AHSOKA_OK 0
@@ -81,6 +81,22 @@ extern "C" {
  *  - genotype (optional, may be NULL): allele dosage per allele, same indexing
  *    as allele_off.  NULL reproduces the reference literal {0:1,1:1}
  *    (src/alignmentstoreadset.cpp:340-344).
+ *  - read_flags (optional, may be NULL): per alignment, bit 0 =
+ *    `alignment.id*100 > 90` evaluated as the reference does, in single
+ *    precision on the float identity (src/alignmentstoreadset.cpp:245 --
+ *    NOT the truncated read_mapq: 0.905f*100 = 90.5 > 90 but (int) = 90).
+ *    S2 adds a variant to an EXISTING Read only from alignments with this bit.
+ *    NULL derives the bit as read_mapq > 90 (exact unless an identity lies
+ *    strictly between 0.90 and 0.91).  ahsoka_ingest / ahsoka_synth_batch
+ *    always fill it.
+ *  - s1_order (optional, may be NULL): per chain the B bubble ids in the order
+ *    S1 visits them, i.e. the iteration order of the chain's copied
+ *    unordered_map<int, vector<vector<int>>> (src/alignmentstoreadset.cpp:76,90;
+ *    quirk Q2).  The order decides which of several same-name alignments
+ *    creates the S1 Read and with it the Read's mapq for the S1b filter.
+ *    Indexed like bubble_off.  NULL = the order libstdc++ gives a map filled
+ *    with the keys 0..B-1 ascending (what ChainsToReadsetDetailed does,
+ *    src/chainstoreadset.cpp:171-198), computed by the library.
  */
 typedef struct ahsoka_chain_batch {
   int32_t n_chains;
@@ -98,6 +114,8 @@ typedef struct ahsoka_chain_batch {
   const int32_t* rnode;       /* [SL]      chain-local node index or -1       */
   const int32_t* read_mapq;   /* [SR]                                         */
   const int32_t* read_name;   /* [SR]      chain-local dense name id          */
+  const uint8_t* read_flags;  /* [SR] or NULL   bit0: float(id)*100 > 90 (:245) */
+  const int32_t* s1_order;    /* [SB] or NULL   S1 bubble visiting order (:90)  */
 } ahsoka_chain_batch;
 
 /* Literals of the reference, made parameters. */
@@ -113,6 +131,10 @@ typedef struct ahsoka_phase_params {
                                  convention (i-th entry <-> i-th covMap cluster)   */
   int32_t device;             /* HIP device ordinal                                */
   int32_t want_stages;        /* !=0: also return the per-stage dumps below        */
+  int32_t max_slots;          /* 0 = automatic.  >0 caps the number of chains in flight
+                                 per size class (workgroups of the persistent grid, each
+                                 with its own slot of HBM working state): a memory knob;
+                                 results do not depend on it                          */
 } ahsoka_phase_params;
 
 /*

@@ -577,12 +577,26 @@ void phase_chain(const ChainView& cv, const ahsoka_phase_params& prm, bool stage
   }
   auto name_of = [&](int r) { return bt->read_name[cv.r0 + r]; };
   auto mapq_of = [&](int r) { return bt->read_mapq[cv.r0 + r]; };
+  // `(alignment.id*100) > 90` of :245 is a FLOAT compare on the identity, not on
+  // the truncated mapq: the batch carries its outcome (bit 0 of read_flags)
+  auto id_gt90 = [&](int r) { return bt->read_flags ? (bt->read_flags[cv.r0 + r] & 1) != 0 : mapq_of(r) > 90; };
 
   // ---- S1 (:90-135) ------------------------------------------------------
-  // The reference iterates bubbles in unordered_map order (quirk Q2); the S1
-  // readset is only consumed through order-independent queries below.
+  // The reference iterates a copy of the chain's unordered_map (:76,:90, quirk
+  // Q2).  The order decides which of several same-name alignments creates the
+  // Read (and so the Read's mapq): the batch carries it (s1_order, pinned on the
+  // compiled reference by tests/test_ingest_golden.py); without it, the order a
+  // libstdc++ map filled with 0..B-1 gives (src/chainstoreadset.cpp:171-198).
+  std::vector<int> s1_order;
+  if (bt->s1_order) s1_order.assign(bt->s1_order + cv.b0, bt->s1_order + cv.b1);
+  else {
+    std::unordered_map<int, std::vector<std::vector<int>>> bubblemap;
+    for (int k = 0; k < B; k++) bubblemap[k];
+    auto chainmap = std::make_pair(cv.c, bubblemap);
+    for (auto& kv : chainmap.second) s1_order.push_back(kv.first);
+  }
   OReadSet readset;
-  for (int k = 0; k < B; k++)
+  for (int k : s1_order)
     for (int a = 0; a < cv.nalleles(k); a++) {
       std::vector<int> path = cv.apath(k, a);
       for (int r = 0; r < R; r++) {
@@ -625,9 +639,7 @@ void phase_chain(const ChainView& cv, const ahsoka_phase_params& prm, bool stage
           ORead rd{name_of(r), mapq_of(r), {}};
           rd.add_variant(boundary, a);
           partial.add(rd);
-        } else if (!partial.reads[idx].has_pos(boundary) && mapq_of(r) > 90) {
-          // :245 tests float(id)*100 > 90; with min_mapq > 90 reads failing it
-          // are dropped by S2b anyway (DESIGN.md, quirk list)
+        } else if (!partial.reads[idx].has_pos(boundary) && id_gt90(r)) {  // :245
           partial.reads[idx].add_variant(boundary, a);
         }
       }

@@ -11,7 +11,8 @@
  *     CHAIN <id> <nbubbles>
  *     BUBBLE <chain> <bubble id> <source> <sink> <ninner> <inner...>
  *     ALLELE <chain> <bubble id> <allele> <n> <node...> | <sign...>
- *     ALN <chain> <name> <mapq> <copies> <n> <node...>
+ *     ALN <chain> <name> <mapq> <id*100 > 90> <copies> <n> <node...>
+ *     S1ORDER <chain> <bubble ids in the order S1 visits them>
  *     ORDER <chain ids in size_sorting order>
  *
  * and, through the extracted-at-build-time slice of is_subset
@@ -112,11 +113,20 @@ int main(int argc, char** argv) {
       while (j < v.size() && v[j].name == v[i].name && v[j].nodes == v[i].nodes) j++;
       int mapq = v[i].id * 100;  // the implicit float->int of the Read ctor, :117
       vector<int> raw = v[i].getRawIds();
-      printf("ALN %d %s %d %zu %zu", chain, v[i].name.c_str(), mapq, j - i, raw.size());
+      int gt90 = (v[i].id * 100) > 90;  // the float compare of :245 on the reference's own field
+      printf("ALN %d %s %d %d %zu %zu", chain, v[i].name.c_str(), mapq, gt90, j - i, raw.size());
       for (int nd : raw) printf(" %d", nd);
       printf("\n");
       i = j;
     }
+  }
+  // S1 walks a COPY of the chain's bubble map (src/alignmentstoreadset.cpp:76,90):
+  // same copy expression here, then the map's own iteration order
+  for (auto& size : size_sorting) {
+    auto chainmap = make_pair(size.second, pathToAlleles[size.second]);
+    printf("S1ORDER %d", chainmap.first);
+    for (auto& bubblemap : chainmap.second) printf(" %d", bubblemap.first);
+    printf("\n");
   }
   printf("ORDER");
   for (auto& s : size_sorting) printf(" %d", s.second);

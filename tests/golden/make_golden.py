@@ -72,6 +72,85 @@ def toy():
     return gfa, "\n".join(lines) + "\n"
 
 
+def simple_chain(base, B):
+    """S and L lines of B simple biallelic bubbles in series on nodes base..base+3B"""
+    S = [f"S\t{utg(base + x)}\tA" for x in range(3 * B + 1)]
+    L = []
+    for k in range(B):
+        s = base + 3 * k
+        for a, b in [(s, s + 1), (s, s + 2), (s + 1, s + 3), (s + 2, s + 3)]:
+            L += link(a, "+", b, "+")
+    return S, L
+
+
+def multi():
+    """Reads with SEVERAL alignments under one name (GraphAligner split alignments),
+    built so that the two order/precision details of the reference decide the result:
+
+    * S1 visits bubbles in unordered_map order (src/alignmentstoreadset.cpp:76,90) and
+      the first hit creates the Read, fixing its mapq for the S1b filter (:117,158);
+    * S2 adds a variant to an existing Read only if `alignment.id*100 > 90` in FLOAT
+      (:245): 0.905 passes although (int)(0.905f*100) == 90.
+
+    The reference numbers the 20-bubble chain (nodes 201..261) as chain 0 with bubble k
+    = {src 261-3k, inner 259-3k | 260-3k, sink 258-3k}, the 6-bubble chain (nodes
+    101..119) as chain 1 with bubble k = {119-3k, 117-3k | 118-3k, 116-3k}
+    (BUBBLE lines of multi.ref.txt); S1ORDER is 19..13,0..12 resp. 5..0."""
+    S1, L1 = simple_chain(101, 6)
+    S2, L2 = simple_chain(201, 20)
+    gfa = "\n".join(S1 + S2 + L1 + L2) + "\n"
+
+    def full(top, k0, k1, alleles):  # bubbles k0..k1 of the chain whose bubble 0 source is `top`
+        nodes = [top - 3 * k0]
+        for k, a in zip(range(k0, k1 + 1), alleles):
+            nodes += [top - 2 - 3 * k + a, top - 3 - 3 * k]
+        return nodes
+
+    def inner(top, k, a):
+        return top - 2 - 3 * k + a
+
+    reads = []
+    # ---- chain 0 (top 261) ----
+    h0 = [0, 1, 1, 0, 0, 1, 0, 1, 1]
+    h1 = [1 - x for x in h0]
+    for i, (k0, k1, h, ident) in enumerate([(0, 4, h0, "0.97"), (0, 5, h1, "0.96"), (2, 7, h0, "0.99"), (3, 8, h1, "0.95"),
+                                            (1, 6, h0, "0.94"), (4, 8, h1, "0.98"), (0, 3, h1, "0.93"), (5, 8, h0, "0.97")]):
+        reads.append((f"a{i}", full(261, k0, k1, h[k0:k1 + 1]), ident))
+    # mB: a 0.95 alignment over bubbles 2,3 and a 0.905 alignment touching only the inner node of
+    # bubble 10 (nobody else covers 10): position 10 is phased iff the float guard of :245 is used
+    reads.append(("mB", full(261, 2, 3, [1, 0]), "0.95"))
+    reads.append(("mB", [inner(261, 10, 0)], "0.905"))
+    # mD: D1 (0.96) over bubbles 0,1 and D2 (0.92) over bubbles 11,12.  In S1 order (.., 0, 1, .., 11, 12)
+    # D1 creates the Read => mapq 96 => kept => last position 12 = maxpos is a boundary => S2 visits 12 and
+    # 13.  (Reverse order would make D2 the creator: mapq 92, filtered, 12 and 13 never visited.)
+    reads.append(("mD", full(261, 0, 1, [0, 1]), "0.96"))
+    reads.append(("mD", full(261, 11, 12, [0, 0]), "0.92"))
+    # partial-only coverage of bubbles 12 and 13 (inner nodes, never source AND sink)
+    reads.append(("p1", [inner(261, 12, 0), inner(261, 13, 1)], "0.97"))
+    reads.append(("p2", [inner(261, 12, 1), inner(261, 13, 0)], "0.98"))
+    reads.append(("p3", [inner(261, 12, 0), inner(261, 13, 1)], "0.95"))
+    # ---- chain 1 (top 119) ----
+    g0 = [1, 0, 0, 1, 1]
+    g1 = [1 - x for x in g0]
+    for i, (k0, k1, h, ident) in enumerate([(0, 3, g0, "0.97"), (0, 3, g1, "0.96"), (1, 3, g0, "0.99"), (2, 3, g1, "0.95")]):
+        # full matches end at bubble 3 (last position 3: boundaries 3,4); each read also touches an inner
+        # node of bubbles 4 and 5 -- partial matches only, their sinks 104 / 101 are missing
+        reads.append((f"b{i}", full(119, k0, k1, h[k0:k1 + 1]) + [inner(119, 4, h[4]), inner(119, 5, i & 1)], ident))
+    # mA: A1 (0.92) over bubbles 0,1 comes first in the file, A2 (0.95) over bubbles 4,5.  S1 order is
+    # 5,4,..,0: A2 creates the Read => mapq 95 => kept => last position 5 = maxpos is a boundary => S2
+    # visits bubble 5.  (Ascending order would make A1 the creator: mapq 92, filtered, 5 never visited.)
+    reads.append(("mA", full(119, 0, 1, [0, 1]), "0.92"))
+    reads.append(("mA", full(119, 4, 5, [1, 0]), "0.95"))
+    lines = []
+    for name, nodes, ident in reads:
+        path = "".join(">" + utg(n) for n in nodes)
+        lines.append(f"{name}\t1000\t0\t1000\t+\t{path}\t1000\t0\t1000\t1000\t1000\t60\tNM:i:0\tAS:f:0\tdv:f:0\tid:f:{ident}")
+    return gfa, "\n".join(lines) + "\n"
+
+
+S1_SIZES = list(range(2, 31)) + [47, 59, 60, 97, 127, 128, 199, 257, 500, 541, 1000]
+
+
 def main():
     from ahsoka_amd import capi
 
@@ -83,7 +162,11 @@ def main():
     gfa, gaf = toy()
     open(os.path.join(HERE, "toy.gfa"), "w").write(gfa)
     open(os.path.join(HERE, "toy.gaf"), "w").write(gaf)
-    for stem in ("c1", "toy"):
+    # fixture 2b: several alignments per read name (S1 order, float guard of :245)
+    gfa, gaf = multi()
+    open(os.path.join(HERE, "multi.gfa"), "w").write(gfa)
+    open(os.path.join(HERE, "multi.gaf"), "w").write(gaf)
+    for stem in ("c1", "toy", "multi"):
         out = subprocess.run([REF_DUMP, os.path.join(HERE, stem + ".gfa"), os.path.join(HERE, stem + ".gaf")],
                              capture_output=True, text=True, check=True).stdout
         open(os.path.join(HERE, stem + ".ref.txt"), "w").write(out)
@@ -91,6 +174,19 @@ def main():
         side = os.path.join(HERE, stem + "-alignment_identities.txt")
         if os.path.exists(side):
             os.remove(side)
+    # fixture 2c: S1 bubble visiting order (iteration order of the reference's copied
+    # unordered_map, src/alignmentstoreadset.cpp:76,90) for chains of many sizes.  The GFA
+    # text is the product's deterministic generator (regenerated by the test, not stored);
+    # stored: the S1ORDER line the reference build printed for it.
+    import tempfile
+    with tempfile.TemporaryDirectory() as td, open(os.path.join(HERE, "s1order.ref.txt"), "w") as f:
+        for B in S1_SIZES:
+            g, a = os.path.join(td, "x.gfa"), os.path.join(td, "x.gaf")
+            capi.synth_write_text(g, a, n_chains=1, n_bubbles=B, n_reads=0, seed=1)
+            out = subprocess.run([REF_DUMP, g, a], capture_output=True, text=True, check=True).stdout
+            line = [ln for ln in out.split("\n") if ln.startswith("S1ORDER ")]
+            assert len(line) == 1
+            f.write(f"B {B} " + " ".join(line[0].split()[2:]) + "\n")
     # fixture 3: is_subset vectors from the reference's compiled function
     L = C.CDLL(REF_LIB)
     i32p = C.POINTER(C.c_int32)

@@ -9,7 +9,7 @@ from ahsoka_amd import capi
 
 def random_batch(seed, n_chains=4, max_bubbles=14, max_reads=120, max_alleles=5, dup_paths=False):
     rng = np.random.default_rng(seed)
-    A = {k: [] for k in ("chain_id", "apath_node", "node_id", "rnode", "read_mapq", "read_name")}
+    A = {k: [] for k in ("chain_id", "apath_node", "node_id", "rnode", "read_mapq", "read_name", "read_flags", "s1_order")}
     off = {k: [0] for k in ("bubble_off", "allele_off", "apath_off", "node_off", "read_off", "rnode_off")}
     next_id = 1
     for c in range(n_chains):
@@ -38,6 +38,7 @@ def random_batch(seed, n_chains=4, max_bubbles=14, max_reads=120, max_alleles=5,
                 off["apath_off"].append(len(A["apath_node"]))
             off["allele_off"].append(len(off["apath_off"]) - 1)
         off["bubble_off"].append(len(off["allele_off"]) - 1)
+        A["s1_order"].extend(rng.permutation(B).tolist())  # any visiting order is legal input
         A["node_id"].extend(range(next_id, next_id + n_local))
         next_id += n_local
         off["node_off"].append(len(A["node_id"]))
@@ -68,13 +69,16 @@ def random_batch(seed, n_chains=4, max_bubbles=14, max_reads=120, max_alleles=5,
                     path.append(path[0])  # revisits a node
             A["rnode"].extend(path)
             off["rnode_off"].append(len(A["rnode"]))
-            A["read_mapq"].append(int(rng.integers(88, 101)))
+            mq = int(rng.integers(88, 101))
+            A["read_mapq"].append(mq)
+            # float(id)*100 > 90: implied by the truncated value except at exactly 90
+            A["read_flags"].append(int(mq > 90 or (mq == 90 and rng.random() < 0.5)))
             if names and rng.random() < 0.1:
                 names.append(names[int(rng.integers(0, len(names)))])
             else:
                 names.append(max(names) + 1 if names else 0)
         A["read_name"].extend(names)
         off["read_off"].append(len(A["read_mapq"]))
-    arrays = {k: np.asarray(v, dtype=np.int32) for k, v in A.items()}
+    arrays = {k: np.asarray(v, dtype=np.uint8 if k == "read_flags" else np.int32) for k, v in A.items()}
     arrays.update({k: np.asarray(v, dtype=np.int64) for k, v in off.items()})
     return capi.ChainBatch(arrays=arrays)

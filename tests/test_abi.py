@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     L = capi.lib()
     for name in declared_symbols():
         assert hasattr(L, name), name
-    assert L.ahsoka_abi_version() == 1
+    assert L.ahsoka_abi_version() == 2
 
 
 def test_default_params_are_the_reference_literals():

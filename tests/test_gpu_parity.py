@@ -187,6 +187,161 @@ def test_c5_skewed_sample():
     assert np.diff(b.arrays()["bubble_off"]).max() > 64
 
 
+def test_multi_alignment_fixture():
+    """reads with several alignments under one name: the S1 visiting order (:76,90) and the
+    float guard `id*100 > 90` (:245) decide which positions are phased (tests/golden/multi.*)"""
+    from test_multi_alignment import check_expected, multi_batch
+    g, _ = _compare(multi_batch(), capi.default_params(want_stages=1))
+    check_expected(g)
+    # NULL s1_order = the library derives the reference's order itself: same result
+    g2, _ = _compare(multi_batch(s1_order=None), capi.default_params(want_stages=1))
+    np.testing.assert_array_equal(g.hap_allele, g2.hap_allele)
+    np.testing.assert_array_equal(g.pos, g2.pos)
+    # NULL read_flags = documented fallback (guard on the truncated identity): position 10 is lost
+    g3, _ = _compare(multi_batch(read_flags=None), capi.default_params(want_stages=1))
+    assert 10 not in g3.chain_pos(0).tolist()
+
+
+def test_slot_reuse_c5_all_stages():
+    """the persistent grid re-uses a slot's HBM state (W, IC, LV, NZ, threading tables) for
+    chain after chain: 1500 chains of the power-law config through at most 16 slots per size
+    class, every stage against the oracle"""
+    cfg = dict(capi.CONFIGS["c5"])
+    cfg["n_chains"] = 1500
+    b = capi.synth_batch(**cfg)
+    _compare(b, capi.default_params(want_stages=1, max_slots=16), n_threads=16)
+
+
+def test_slot_reuse_large_then_small_chain():
+    """ONE slot, chains of very different size in the same size class, largest first (the queue
+    order): stale live/non-zero bitmaps, clique bits or row maxima of a large chain must not
+    leak into the smaller chain that follows it in the slot"""
+    big = capi.synth_batch(n_chains=2, n_bubbles=50, n_reads=1000, seed=0xA450CA03).arrays()
+    small = capi.synth_batch(n_chains=3, n_bubbles=30, n_reads=560, seed=77).arrays()
+    mid = capi.synth_batch(n_chains=2, n_bubbles=40, n_reads=760, seed=78).arrays()
+    b = _concat([small, big, mid])
+    g, o = _compare(b, capi.default_params(want_stages=1, max_slots=1), n_threads=8)
+    assert g.n_reads.max() > 1.6 * g.n_reads.min() and g.n_reads.min() > g.n_reads.max() // 2  # one size class
+
+
+def test_slot_reuse_ploidy4():
+    """64 tetraploid chains through 8 slots: the threading tables (up to 4096 tuples per
+    position) are slot state too"""
+    b = capi.synth_batch(n_chains=64, n_bubbles=12, n_reads=240, ploidy=4, seed=0xA450CA04)
+    _compare(b, capi.default_params(want_stages=1, ploidy=4, max_slots=8), n_threads=16)
+
+
+def _concat(parts):
+    """concatenate ChainBatch array dicts (chains keep their own local indices)"""
+    out = {}
+    for k in ("chain_id", "apath_node", "node_id", "rnode", "read_mapq", "read_name", "read_flags", "s1_order"):
+        out[k] = np.concatenate([p[k] for p in parts])
+    out["chain_id"] = np.arange(len(out["chain_id"]), dtype=np.int32)
+    for k, dep in (("bubble_off", None), ("allele_off", "bubble_off"), ("apath_off", "allele_off"), ("node_off", None),
+                   ("read_off", None), ("rnode_off", "read_off")):
+        acc, base = [np.zeros(1, dtype=np.int64)], 0
+        for p in parts:
+            acc.append(p[k][1:] + base)
+            base += p[k][-1]
+        out[k] = np.concatenate(acc)
+    return capi.ChainBatch(arrays=out)
+
+
+def test_over_limit_chain_is_reported_per_chain():
+    """a chain beyond a device limit comes back AHSOKA_ST_UNSUPPORTED; the other chains of the
+    batch are phased as usual (the limits: phase_kernels.h)"""
+    ok = capi.synth_batch(n_chains=3, n_bubbles=9, n_reads=80, seed=5).arrays()
+    many_names = capi.synth_batch(n_chains=1, n_bubbles=12, n_reads=4300, seed=6).arrays()   # > 4096 names
+    many_nodes = capi.synth_batch(n_chains=1, n_bubbles=700, n_reads=50, seed=7).arrays()    # 2101 nodes > 2048
+    many_final = capi.synth_batch(n_chains=1, n_bubbles=40, n_reads=3600, seed=8).arrays()   # > 2048 final reads
+    b = _concat([ok, many_names, many_nodes, many_final])
+    g = capi.phase_batch(b, capi.default_params())
+    assert g.status.tolist() == [0, 0, 0, capi.ST_UNSUPPORTED, capi.ST_UNSUPPORTED, capi.ST_UNSUPPORTED]
+    o = ob.phase_batch(capi.ChainBatch(arrays=ok), capi.default_params())
+    np.testing.assert_array_equal(g.hap_allele, o.hap_allele)
+    np.testing.assert_array_equal(g.pos, o.pos)
+    assert g.n_reads[3:].sum() == 0 and g.pos_off[-1] == o.pos_off[-1]
+
+
+def test_c5_full_size_vs_oracle():
+    """BASELINE configs[4] at FULL size on one GPU (50 000 chains, power-law bubble counts,
+    35 000 one-bubble chains that are skipped): every chain bit-exact against the oracle,
+    with 64 slots per size class (heavy slot re-use) and with the automatic slot count"""
+    b = capi.synth_batch(**capi.CONFIGS["c5"])
+    o = ob.phase_batch(b, capi.default_params(), n_threads=16)
+    for slots in (64, 0):
+        g = capi.phase_batch(b, capi.default_params(max_slots=slots))
+        np.testing.assert_array_equal(g.status, o.status)
+        np.testing.assert_array_equal(g.n_reads, o.n_reads)
+        np.testing.assert_array_equal(g.n_iterations, o.n_iterations)
+        np.testing.assert_array_equal(g.pos, o.pos)
+        np.testing.assert_array_equal(g.hap_cluster, o.hap_cluster)
+        np.testing.assert_array_equal(g.hap_allele, o.hap_allele)
+    assert (g.status == capi.ST_PHASED).sum() > 10000 and g.n_reads.max() > 600
+
+
+def _perm_accuracy(h, t):
+    """fraction of positions where the haplotype rows equal the truth rows under the best
+    global assignment of predicted to true haplotypes"""
+    import itertools
+    p = h.shape[0]
+    return max(int((h[list(perm)] == t).all(axis=0).sum()) for perm in itertools.permutations(range(p))) / max(1, h.shape[1])
+
+
+def test_c4_full_size_properties():
+    """BASELINE configs[3] at FULL size (2000 chains x 30 bubbles x 2000 reads, ploidy 4,
+    genotype = truth dosage): idempotence, genotype conformity, agreement with the truth
+    haplotypes, slot re-use at ploidy 4, and bit-exact parity with the oracle on a sample"""
+    cfg = dict(capi.CONFIGS["c4"])
+    b = capi.synth_batch(**cfg)
+    dev = capi.DeviceBatch(b, capi.default_params(ploidy=4))
+    dev.phase()
+    g = dev.download()
+    dev.phase()
+    g2 = dev.download()
+    dev.free()
+    np.testing.assert_array_equal(g.hap_allele, g2.hap_allele)
+    np.testing.assert_array_equal(g.hap_cluster, g2.hap_cluster)
+    np.testing.assert_array_equal(g.n_iterations, g2.n_iterations)
+    assert (g.status == capi.ST_PHASED).all()
+    assert np.diff(g.pos_off).min() >= 25
+    a = b.arrays()
+    truth = capi.synth_truth(**cfg)
+    conform = tot = 0
+    acc = []
+    for c in range(0, 2000, 7):
+        h = g.chain_haps(c)
+        pos = g.chain_pos(c)
+        t = truth[c * 120:(c + 1) * 120].reshape(4, 30)[:, pos]
+        # dosage of allele 1 per position equals the supplied genotype wherever a conform tuple existed
+        conform += int((h.sum(axis=0) == t.sum(axis=0)).sum())
+        tot += h.shape[1]
+        acc.append(_perm_accuracy(h, t))
+    assert conform / tot > 0.9
+    assert np.mean(acc) > 0.6  # (4 haplotypes, 2 % allele errors, reads of ~8 bubbles)
+    # the same chains through 8 slots: identical bits
+    sub = dict(cfg)
+    sub["n_chains"] = 40
+    bs = capi.synth_batch(**sub)
+    gs = capi.phase_batch(bs, capi.default_params(ploidy=4, max_slots=8))
+    for c in range(40):
+        np.testing.assert_array_equal(gs.chain_haps(c), g.chain_haps(c))
+    np.testing.assert_array_equal(gs.n_iterations, g.n_iterations[:40])
+    # oracle on 4 chains spread over the batch (17 s each on one core)
+    idx = [0, 666, 1333, 1999]
+    import concurrent.futures as cf
+
+    def one(c):
+        s1 = dict(cfg)
+        s1["n_chains"] = 1
+        s1["first_chain"] = c
+        return ob.phase_batch(capi.synth_batch(**s1), capi.default_params(ploidy=4))
+    with cf.ThreadPoolExecutor(4) as ex:
+        for c, o in zip(idx, ex.map(one, idx)):
+            np.testing.assert_array_equal(o.chain_haps(0), g.chain_haps(c))
+            assert o.n_iterations[0] == g.n_iterations[c]
+
+
 def test_c3_full_size_properties():
     """BASELINE configs[2] at FULL size (10k chains x 50 bubbles x 1000 reads):
     size-independent properties of a diploid phasing, plus bit-exact parity with

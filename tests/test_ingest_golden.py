@@ -15,7 +15,7 @@ from ahsoka_amd import capi
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("stem", ["c1", "toy"])
+@pytest.mark.parametrize("stem", ["c1", "toy", "multi"])
 def test_dump_equals_reference(stem, tmp_path):
     out = str(tmp_path / "dump.txt")
     capi.ingest_dump(os.path.join(GOLD, stem + ".gfa"), os.path.join(GOLD, stem + ".gaf"), out)
@@ -23,7 +23,7 @@ def test_dump_equals_reference(stem, tmp_path):
 
 
 def _parse(path):
-    chains, alleles, alns, order = {}, {}, {}, []
+    chains, alleles, alns, order, s1 = {}, {}, {}, [], {}
     for ln in open(path):
         t = ln.split()
         if t[0] == "CHAIN":
@@ -32,22 +32,25 @@ def _parse(path):
             n = int(t[4])
             alleles.setdefault((int(t[1]), int(t[2])), []).append(([int(x) for x in t[5:5 + n]], t[6 + n:]))
         elif t[0] == "ALN":
-            n = int(t[5])
-            alns.setdefault(int(t[1]), []).append((t[2], int(t[3]), [int(x) for x in t[6:6 + n]]))
+            n = int(t[6])
+            alns.setdefault(int(t[1]), []).append((t[2], int(t[3]), int(t[4]), [int(x) for x in t[7:7 + n]]))
+        elif t[0] == "S1ORDER":
+            s1[int(t[1])] = [int(x) for x in t[2:]]
         elif t[0] == "ORDER":
             order = [int(x) for x in t[1:]]
-    return chains, alleles, alns, order
+    return chains, alleles, alns, order, s1
 
 
-@pytest.mark.parametrize("stem", ["c1", "toy"])
+@pytest.mark.parametrize("stem", ["c1", "toy", "multi"])
 def test_batch_equals_reference(stem):
-    chains, alleles, alns, order = _parse(os.path.join(GOLD, stem + ".ref.txt"))
+    chains, alleles, alns, order, s1 = _parse(os.path.join(GOLD, stem + ".ref.txt"))
     b = capi.ingest(os.path.join(GOLD, stem + ".gfa"), os.path.join(GOLD, stem + ".gaf"))
     a = b.arrays()
     assert list(a["chain_id"]) == order
     for ci, cid in enumerate(order):
         b0, b1 = a["bubble_off"][ci], a["bubble_off"][ci + 1]
         assert b1 - b0 == chains[cid]
+        assert list(a["s1_order"][b0:b1]) == s1[cid]  # S1 bubble visiting order (:76,90)
         nid = a["node_id"][a["node_off"][ci]:a["node_off"][ci + 1]]
         for k in range(b1 - b0):
             exp = alleles[(cid, k)]
@@ -62,8 +65,9 @@ def test_batch_equals_reference(stem):
         assert r1 - r0 == len(exp_al)
         names = {}
         for r in range(r0, r1):
-            name, mapq, nodes = exp_al[r - r0]
+            name, mapq, gt90, nodes = exp_al[r - r0]
             assert a["read_mapq"][r] == mapq
+            assert a["read_flags"][r] == gt90  # float(id)*100 > 90 (:245)
             loc = a["rnode"][a["rnode_off"][r]:a["rnode_off"][r + 1]]
             back = [int(nid[x]) if x >= 0 else None for x in loc]
             assert all(bk is None or bk == nd for bk, nd in zip(back, nodes)) and len(back) == len(nodes)
@@ -73,11 +77,60 @@ def test_batch_equals_reference(stem):
             assert a["read_name"][r] == names[name]
 
 
+def test_s1_visiting_order_golden(tmp_path):
+    """S1 walks a chain's bubbles in the iteration order of the reference's copied
+    unordered_map (src/alignmentstoreadset.cpp:76,90): the ingest's order for chains of
+    2..1000 bubbles against what the reference build printed (tests/golden/s1order.ref.txt)"""
+    gold = {}
+    for ln in open(os.path.join(GOLD, "s1order.ref.txt")):
+        t = ln.split()
+        gold[int(t[1])] = [int(x) for x in t[2:]]
+    assert len(gold) >= 40 and max(gold) == 1000
+    not_reverse = 0
+    for B, exp in gold.items():
+        assert sorted(exp) == list(range(B))
+        g, a = str(tmp_path / "x.gfa"), str(tmp_path / "x.gaf")
+        capi.synth_write_text(g, a, n_chains=1, n_bubbles=B, n_reads=0, seed=1)
+        out = str(tmp_path / "dump.txt")
+        capi.ingest_dump(g, a, out)
+        line = [ln for ln in open(out) if ln.startswith("S1ORDER ")]
+        assert len(line) == 1 and [int(x) for x in line[0].split()[2:]] == exp, B
+        # the direct generator and the library's NULL default carry the same order
+        sb = capi.synth_batch(n_chains=1, n_bubbles=B, n_reads=0, seed=1).arrays()
+        assert list(sb["s1_order"]) == exp
+        not_reverse += exp != list(range(B - 1, -1, -1))
+    assert not_reverse > 10  # beyond 13 bubbles the table rehashes: not simply reversed
+
+
+def test_dump_live_against_reference_build(tmp_path):
+    """a mid-size synthetic graph through the reference's own parsers, right now"""
+    import subprocess
+    ref_dump = os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "ref_dump")
+    if not os.path.exists(ref_dump):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    g, a = str(tmp_path / "x.gfa"), str(tmp_path / "x.gaf")
+    capi.synth_write_text(g, a, n_chains=7, n_bubbles=0, n_reads=0, b_mode=1, mean_span=10.0, seed=0xA450CA05, first_chain=13)
+    exp = subprocess.run([ref_dump, g, a], capture_output=True, text=True, check=True).stdout
+    out = str(tmp_path / "dump.txt")
+    capi.ingest_dump(g, a, out)
+    assert open(out).read() == exp
+
+
 def test_identity_truncation():
     """(int)(stof(id)*100): 0.935 -> 93, 0.931 -> 93, 1 -> 100, 0.92 -> 92"""
     b = capi.ingest(os.path.join(GOLD, "toy.gfa"), os.path.join(GOLD, "toy.gaf"))
     a = b.arrays()
     assert sorted(set(a["read_mapq"].tolist())) == [92, 93, 94, 95, 96, 97, 98, 99, 100]
+
+
+def test_float_guard_flag():
+    """`alignment.id*100 > 90` (src/alignmentstoreadset.cpp:245) is a float compare: 0.905
+    truncates to mapq 90 but passes the guard; the reference build's ALN line says so"""
+    b = capi.ingest(os.path.join(GOLD, "multi.gfa"), os.path.join(GOLD, "multi.gaf"))
+    a = b.arrays()
+    sel = (a["read_mapq"] == 90)
+    assert sel.sum() == 1 and a["read_flags"][sel][0] == 1
+    assert (a["read_flags"][a["read_mapq"] > 90] == 1).all()
 
 
 def test_parse_errors(tmp_path):
