@@ -338,6 +338,98 @@ constexpr int kFastBatch = AHK_FAST_BATCH;  // live words of a row a wave of the
 #define AHK_P3B_CH 4
 #endif
 constexpr int kP3bChunk = AHK_P3B_CH;  // triangles per load batch of an edge in P3b
+#ifndef AHK_HEAVY
+#define AHK_HEAVY 1  // P3b, edges with long member lists: 1 = member lists in chunks over all lanes; 2 = one wave per edge, lanes = members; 0 = off
+#endif
+#ifndef AHK_HEAVY_MIN
+#define AHK_HEAVY_MIN 48
+#endif
+#ifndef AHK_HEAVY_MAXITEMS
+#define AHK_HEAVY_MAXITEMS 768
+#endif
+constexpr int kHeavyChunk = 16;  // members per chunk (AHK_HEAVY == 1)
+constexpr int kHeavyCap = 128;   // heavy edges per round: their accumulators live in rmask/rolenz
+#ifndef AHK_IC_LATE
+#define AHK_IC_LATE 1  // P3b: load an edge's induced costs only once its delta is known to be non-zero
+#endif
+constexpr int kHeavyMin = AHK_HEAVY_MIN;            // member-list length from which an edge counts as heavy
+constexpr int kHeavyMaxItems = AHK_HEAVY_MAXITEMS;  // beyond that many heavy edges the plain loop keeps every lane busy anyway
+
+// exact 64-bit sum over the 64 lanes (DPP row shifts / broadcasts), result in every lane
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ long long dpp_add_step64(long long v) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(unsigned long long)v, CTRL, ROWMASK, 0xf, false);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)((unsigned long long)v >> 32), CTRL, ROWMASK, 0xf, false);
+  return v + (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+  v = dpp_add_step64<0x111, 0xf>(v);
+  v = dpp_add_step64<0x112, 0xf>(v);
+  v = dpp_add_step64<0x114, 0xf>(v);
+  v = dpp_add_step64<0x118, 0xf>(v);
+  v = dpp_add_step64<0x142, 0xa>(v);
+  v = dpp_add_step64<0x143, 0xc>(v);
+  return (long long)readlane_u64((unsigned long long)v, 63);
+}
+
+// Triangle terms of edge (x,b), b not itself rewritten, over the members L[0..cnt) of ONE
+// list whose pairs (x,w) all get the same new weight Nv (W_PERM for the opposite clique of
+// a merge, W_FORB otherwise): with Nv known at compile time the two "new" terms fold to
+// max(q,0) / max(-q,0) / 0 -- about half the instructions per triangle.  Full chunks of
+// four members run without per-load predicates (each one costs an exec-mask branch) and
+// read their ids with one 8-byte LDS load (L must be 8-byte aligned); padding slots load
+// nothing and read as 0,0: all four terms vanish.
+template <int Nv>
+__device__ __forceinline__ void tri_seg(const int* __restrict__ Wm, int n, int x, int b, const unsigned short* L, int cnt,
+                                        long long& df, long long& dp) {
+  int w0 = 0;
+#if AHK_P3B_SINGLE
+  // a single member (one read opposite a clique): the most common list of all
+  if (cnt == 1) {
+    const int w = L[0];
+    // (W is symmetric: W[x][w] is read as W[w][x] -- row w is the row every edge of this
+    // iteration reads its third edge from, row x would be one more HBM line per row x)
+    const int ov = Wm[(unsigned)(w * n + x)], wb = Wm[(unsigned)(w * n + b)];
+    df += icf_term(Nv, wb) - icf_term(ov, wb);
+    dp += icp_term(Nv, wb) - icp_term(ov, wb);
+    return;
+  }
+#endif
+#if AHK_P3B_FULL
+  static_assert(kP3bChunk == 4, "full-chunk loop reads four u16 ids at once");
+  for (; w0 + 4 <= cnt; w0 += 4) {
+    const uint2 pk = *reinterpret_cast<const uint2*>(L + w0);
+    const int wq[4] = {(int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16)};
+    int ovv[4], wbv[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      ovv[c] = Wm[(unsigned)(x * n + wq[c])];
+      wbv[c] = Wm[(unsigned)(wq[c] * n + b)];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      df += icf_term(Nv, wbv[c]) - icf_term(ovv[c], wbv[c]);
+      dp += icp_term(Nv, wbv[c]) - icp_term(ovv[c], wbv[c]);
+    }
+  }
+#endif
+  for (; w0 < cnt; w0 += kP3bChunk) {
+    int ovv[kP3bChunk], wbv[kP3bChunk];
+#pragma unroll
+    for (int c = 0; c < kP3bChunk; c++) {
+      const bool ok = w0 + c < cnt;
+      const int w = ok ? (int)L[w0 + c] : 0;
+      ovv[c] = ok ? Wm[(unsigned)(x * n + w)] : 0;
+      wbv[c] = ok ? Wm[(unsigned)(w * n + b)] : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < kP3bChunk; c++) {
+      df += icf_term(Nv, wbv[c]) - icf_term(ovv[c], wbv[c]);
+      dp += icp_term(Nv, wbv[c]) - icp_term(ovv[c], wbv[c]);
+    }
+  }
+}
+
 #ifndef AHK_WAVES_PER_SIMD
 #define AHK_WAVES_PER_SIMD 5
 #endif
@@ -359,7 +451,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
   unsigned long long* rmask = (unsigned long long*)(multiw + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][32] role masks per 64-column word
   unsigned long long* rolenz = rmask + 4 * 32;             // [4][32] OR of the members' nz-rows
   unsigned char* role = (unsigned char*)(rolenz + 4 * 32);  // [nmax]
-  __shared__ int s_chain, s_cnt[4], s_nd, s_items;
+  __shared__ int s_chain, s_cnt[4], s_nd, s_items, s_nh;
+  __shared__ unsigned short s_pref[4][32];
 #ifdef AHK_TIMING
   __shared__ int s_chg;
 #endif
@@ -537,6 +630,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           const int w = w0 + lane;
           const bool nz = w < n && Wm[(unsigned)(a * n + w)] != 0;
           const unsigned long long mk = __ballot(nz);
+
           const unsigned long long mh = __ballot(nz && w > a);
           if (nz) nbr[deg + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)w;
           if (nz && w > a) nhi[dhi + __popcll(mh & ((1ull << lane) - 1ull))] = (unsigned short)w;
@@ -594,7 +688,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     }
     for (int u = tid; u < (n + 31) / 32; u += kBlock) multiw[u] = 0;
     if (tid < 4) s_cnt[tid] = 0;
-    if (tid == 0) { s_nd = 0; s_items = 0; }
+    if (tid == 0) { s_nd = 0; s_items = 0; s_nh = 0; }
     __syncthreads();
 #ifdef AHK_DIAG
     if (lds.stop_after == 2) continue;
@@ -784,10 +878,6 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             if (fb && !fa) r = ROLE_FB;
           }
           role[z] = (unsigned char)r;
-          if (r == ROLE_A) listA[atomicAdd(&s_cnt[0], 1)] = (unsigned short)z;
-          else if (r == ROLE_B) listB[atomicAdd(&s_cnt[1], 1)] = (unsigned short)z;
-          else if (r == ROLE_FA) listFa[atomicAdd(&s_cnt[2], 1)] = (unsigned short)z;
-          else if (r == ROLE_FB) listFb[atomicAdd(&s_cnt[3], 1)] = (unsigned short)z;
         }
         const unsigned long long m1 = __ballot(r == ROLE_A), m2 = __ballot(r == ROLE_B);
         const unsigned long long m3 = __ballot(r == ROLE_FA), m4 = __ballot(r == ROLE_FB);
@@ -798,6 +888,27 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           rmask[2 * 32 + k] = m3;
           rmask[3 * 32 + k] = m4;
         }
+      }
+      __syncthreads();
+      // member lists in ASCENDING read order, straight from the masks: wave R scans the word
+      // popcounts of role R, then every member finds its slot by a popcount below its bit
+      // (consecutive list entries are neighbouring columns: the row accesses W[x][w] over a
+      // list touch few lines, and the heavy-edge pass relies on the order)
+      {
+        const unsigned long long mw = lane < nw ? rmask[wv * 32 + lane] : 0ull;
+        const int pc = __popcll(mw);
+        const int incl = wave_scan_i(pc);
+        if (lane < 32) s_pref[wv][lane] = (unsigned short)(incl - pc);
+        if (lane == 63) s_cnt[wv] = incl;
+      }
+      __syncthreads();
+      for (int z = tid; z < n; z += kBlock) {
+        const int r = role[z];
+        if (r == ROLE_NONE) continue;
+        const int k = z >> 6;
+        const int slot = (int)s_pref[r - 1][k] + __popcll(rmask[(r - 1) * 32 + k] & ((1ull << (z & 63)) - 1ull));
+        unsigned short* Lz = r == ROLE_A ? listA : r == ROLE_B ? listB : r == ROLE_FA ? listFa : listFb;
+        Lz[slot] = (unsigned short)z;
       }
       __syncthreads();
       const int nA = s_cnt[0], nB = s_cnt[1], nFa = s_cnt[2], nFb = s_cnt[3];
@@ -966,15 +1077,63 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         sumM += M;
         s_items_last = M;
 #endif
+#if AHK_HEAVY
+        // Heavy edges.  The member lists an edge (x,b) must walk depend only on the role of x:
+        // A: B u Fb, B: A u Fa, FA: B, FB: A.  When one clique is large and the other a single
+        // read -- the shape of the late iterations: 7 % of them, two thirds of the loop's time
+        // -- the ~100 edges of the single read's row each walk 100-300 members, four per
+        // dependent load batch, on one or two waves, while every other lane has one triangle
+        // per edge and then waits at the barrier.  Such edges go to a list of their own (hl)
+        // and are handled after the plain loop.
+        unsigned int heavy = 0u;  // bit per role of x
+        {
+          const int lenA = nB + nFb, lenB = nA + nFa;
+          if (lenA >= kHeavyMin) heavy |= 1u << ROLE_A;
+          if (lenB >= kHeavyMin) heavy |= 1u << ROLE_B;
+          if (nB >= kHeavyMin) heavy |= 1u << ROLE_FA;
+          if (nA >= kHeavyMin) heavy |= 1u << ROLE_FB;
+        }
+        unsigned int* hl = items_glb + (size_t)(ws.nmax * ws.nmax / 2);  // (overflow items use the first half at most)
+        int nh = 0;
+        if (heavy != 0u) {  // uniform
+          for (int i0 = 0; i0 < M; i0 += kBlock) {
+            const int i = i0 + tid;
+            unsigned int it = 0u;
+            bool hv = false;
+            if (i < M) {
+              it = i < cap ? items_lds[i] : items_glb[i - cap];
+              hv = ((heavy >> (it >> 28)) & 1u) && ((it >> 24) & 7u) == (unsigned)ROLE_NONE;
+            }
+            const unsigned long long mk = __ballot(hv);
+            if (mk != 0ull) {
+              int base = 0;
+              if (lane == 0) base = atomicAdd(&s_nh, __popcll(mk));
+              base = __builtin_amdgcn_readlane(base, 0);
+              if (hv) hl[base + mask_rank(mk)] = it;
+            }
+          }
+          __syncthreads();
+          nh = s_nh;
+          if (nh > kHeavyMaxItems) {  // enough heavy edges to keep every lane busy: the plain loop does them
+            nh = 0;
+            heavy = 0u;
+          }
+        }
+#endif
         for (int i = tid; i < M; i += kBlock) {
           const unsigned int it = i < cap ? items_lds[i] : items_glb[i - cap];
           const int rx = (int)(it >> 28), rb = (int)((it >> 24) & 7u);
+#if AHK_HEAVY
+          if (((heavy >> rx) & 1u) && rb == ROLE_NONE) continue;  // one wave per such edge, below
+#endif
           const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
           const unsigned ici = ic_index(x, b, n);
-          // speculative: only ~8 % of the candidates change, but loading the entry
-          // after the triangle terms (a dependent load) measured 4 % slower although it
-          // cuts the loop's HBM lines by a quarter -- the loop is latency-bound
+          // Only ~4 % of the candidates change.  The kernel moves HBM lines at the rate the
+          // memory system can deliver them for this access pattern, so the entry (one 128-B
+          // line for 16 useful bytes) is loaded only once the delta is known to be non-zero.
+#if !AHK_IC_LATE
           IcPair ic = IC[ici];
+#endif
           long long df = 0, dp = 0;
 #if defined(AHK_TIMING) && AHK_TIMING > 1
           AHK_T(8);
@@ -986,64 +1145,12 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             const int n2 = rx == ROLE_A ? nFb : (rx == ROLE_B ? nFa : 0);
 #if AHK_P3B_SPECIAL
             if (rb == ROLE_NONE) {
-              // The common case: b is not itself rewritten, so the third edge (w,b) keeps
-              // its weight, and within one member list the new weight of (x,w) is one
-              // constant -- W_PERM for the opposite clique of a merge, W_FORB otherwise.
-              // With that constant known at compile time the two "new" terms fold to
-              // max(q,0) / max(-q,0) / 0: about half the instructions per triangle.
-              // (Padding slots load nothing and read as 0,0: all four terms vanish.)
-              auto seg = [&](auto nv_tag, const unsigned short* L, int cnt) {
-                constexpr int Nv = decltype(nv_tag)::value;
-                int w0 = 0;
-#if AHK_P3B_SINGLE
-                // a single member (one read opposite a clique): the most common list of all
-                if (cnt == 1) {
-                  const int w = L[0];
-                  const int ov = Wm[(unsigned)(x * n + w)], wb = Wm[(unsigned)(w * n + b)];
-                  df += icf_term(Nv, wb) - icf_term(ov, wb);
-                  dp += icp_term(Nv, wb) - icp_term(ov, wb);
-                  return;
-                }
-#endif
-#if AHK_P3B_FULL
-                // full chunks: no per-load predicate (each one costs an exec-mask branch),
-                // the four member ids come with one 8-byte LDS read
-                static_assert(kP3bChunk == 4, "full-chunk loop reads four u16 ids at once");
-                for (; w0 + 4 <= cnt; w0 += 4) {
-                  const uint2 pk = *reinterpret_cast<const uint2*>(L + w0);
-                  const int wq[4] = {(int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16)};
-                  int ovv[4], wbv[4];
-#pragma unroll
-                  for (int c = 0; c < 4; c++) {
-                    ovv[c] = Wm[(unsigned)(x * n + wq[c])];
-                    wbv[c] = Wm[(unsigned)(wq[c] * n + b)];
-                  }
-#pragma unroll
-                  for (int c = 0; c < 4; c++) {
-                    df += icf_term(Nv, wbv[c]) - icf_term(ovv[c], wbv[c]);
-                    dp += icp_term(Nv, wbv[c]) - icp_term(ovv[c], wbv[c]);
-                  }
-                }
-#endif
-                for (; w0 < cnt; w0 += kP3bChunk) {
-                  int ovv[kP3bChunk], wbv[kP3bChunk];
-#pragma unroll
-                  for (int c = 0; c < kP3bChunk; c++) {
-                    const bool ok = w0 + c < cnt;
-                    const int w = ok ? (int)L[w0 + c] : 0;
-                    ovv[c] = ok ? Wm[(unsigned)(x * n + w)] : 0;
-                    wbv[c] = ok ? Wm[(unsigned)(w * n + b)] : 0;
-                  }
-#pragma unroll
-                  for (int c = 0; c < kP3bChunk; c++) {
-                    df += icf_term(Nv, wbv[c]) - icf_term(ovv[c], wbv[c]);
-                    dp += icp_term(Nv, wbv[c]) - icp_term(ovv[c], wbv[c]);
-                  }
-                }
-              };
-              if (merge && (rx == ROLE_A || rx == ROLE_B)) seg(std::integral_constant<int, W_PERM>{}, L1, n1);
-              else seg(std::integral_constant<int, W_FORB>{}, L1, n1);
-              if (n2 > 0) seg(std::integral_constant<int, W_FORB>{}, L2, n2);
+              // The common case: b is not itself rewritten, so the third edge (w,b) keeps its
+              // weight, and within one member list the new weight of (x,w) is one constant
+              // (tri_seg).
+              if (merge && (rx == ROLE_A || rx == ROLE_B)) tri_seg<W_PERM>(Wm, n, x, b, L1, n1, df, dp);
+              else tri_seg<W_FORB>(Wm, n, x, b, L1, n1, df, dp);
+              if (n2 > 0) tri_seg<W_FORB>(Wm, n, x, b, L2, n2, df, dp);
             } else
 #endif
             {
@@ -1099,6 +1206,9 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           AHK_T(9);
 #endif
           if (df == 0 && dp == 0) continue;
+#if AHK_IC_LATE
+          IcPair ic = IC[ici];
+#endif
           ic.f += df;
           ic.p += dp;
           IC[ici] = ic;
@@ -1119,6 +1229,159 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           AHK_T(10);
 #endif
         }
+#if AHK_HEAVY == 1
+        // Heavy edges in chunks: the member lists are cut into chunks of kHeavyChunk that are
+        // dealt out over all 256 lanes (consecutive lanes = consecutive edges of a row, same
+        // chunk: the coalescing of the plain loop); partial sums are exact integers, added
+        // into per-edge LDS accumulators (kHeavyCap edges per round), then applied one lane
+        // per edge.  75 dependent load batches of one lane become ~26 of every lane.
+        if (nh > 0) {  // uniform
+          unsigned long long* hacc = rmask;  // [2 * kHeavyCap]: rmask and rolenz are dead after P3a
+          for (int r0 = 0; r0 < nh; r0 += kHeavyCap) {
+            const int nr = nh - r0 < kHeavyCap ? nh - r0 : kHeavyCap;
+            for (int k = tid; k < 2 * nr; k += kBlock) hacc[k] = 0ull;
+            __syncthreads();
+            // chunks per edge: the largest count over the heavy roles spans the grid
+            int chmax = 0;
+            {
+              const int cA = (nB + kHeavyChunk - 1) / kHeavyChunk + (nFb + kHeavyChunk - 1) / kHeavyChunk;
+              const int cB = (nA + kHeavyChunk - 1) / kHeavyChunk + (nFa + kHeavyChunk - 1) / kHeavyChunk;
+              const int cFa = (nB + kHeavyChunk - 1) / kHeavyChunk, cFb = (nA + kHeavyChunk - 1) / kHeavyChunk;
+              if ((heavy >> ROLE_A) & 1u) chmax = cA;
+              if (((heavy >> ROLE_B) & 1u) && cB > chmax) chmax = cB;
+              if (((heavy >> ROLE_FA) & 1u) && cFa > chmax) chmax = cFa;
+              if (((heavy >> ROLE_FB) & 1u) && cFb > chmax) chmax = cFb;
+            }
+            const int V = nr * chmax;
+            for (int v = tid; v < V; v += kBlock) {
+              const int c = v / nr, hh = v - c * nr;
+              const unsigned int it = hl[r0 + hh];
+              const int rx = (int)(it >> 28);
+              const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
+              const unsigned short* L1 = (rx == ROLE_A || rx == ROLE_FA) ? listB : listA;
+              const int n1 = (rx == ROLE_A || rx == ROLE_FA) ? nB : nA;
+              const unsigned short* L2 = rx == ROLE_A ? listFb : listFa;
+              const int n2 = rx == ROLE_A ? nFb : (rx == ROLE_B ? nFa : 0);
+              const int ch1 = (n1 + kHeavyChunk - 1) / kHeavyChunk, ch2 = (n2 + kHeavyChunk - 1) / kHeavyChunk;
+              long long df = 0, dp = 0;
+              if (c < ch1) {
+                const int o = c * kHeavyChunk;
+                const int cnt = n1 - o < kHeavyChunk ? n1 - o : kHeavyChunk;
+                if (merge && (rx == ROLE_A || rx == ROLE_B)) tri_seg<W_PERM>(Wm, n, x, b, L1 + o, cnt, df, dp);
+                else tri_seg<W_FORB>(Wm, n, x, b, L1 + o, cnt, df, dp);
+              } else if (c < ch1 + ch2) {
+                const int o = (c - ch1) * kHeavyChunk;
+                const int cnt = n2 - o < kHeavyChunk ? n2 - o : kHeavyChunk;
+                tri_seg<W_FORB>(Wm, n, x, b, L2 + o, cnt, df, dp);
+              }
+              if (df != 0) atomicAdd(&hacc[2 * hh], (unsigned long long)df);
+              if (dp != 0) atomicAdd(&hacc[2 * hh + 1], (unsigned long long)dp);
+            }
+            __syncthreads();
+            for (int hh = tid; hh < nr; hh += kBlock) {
+              const long long df = (long long)hacc[2 * hh], dp = (long long)hacc[2 * hh + 1];
+              if (df == 0 && dp == 0) continue;
+              const unsigned int it = hl[r0 + hh];
+              const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
+              const unsigned ici = ic_index(x, b, n);
+              IcPair ic = IC[ici];
+              ic.f += df;
+              ic.p += dp;
+              IC[ici] = ic;
+              IC[ic_index(b, x, n)] = ic;
+#ifdef AHK_TIMING
+              atomicAdd(&s_chg, 1);
+#endif
+              const unsigned long long c1 = mkkey(ic.f, x, b), c2 = mkkey(ic.p, x, b);
+              fold_key(&bestF[x], c1);
+              fold_key(&bestP[x], c2);
+              fold_key(&bestF[b], c1);
+              fold_key(&bestP[b], c2);
+            }
+            __syncthreads();
+          }
+        }
+#elif AHK_HEAVY == 2
+        // One wave per heavy edge (x,b); lanes = members w of x's opposite lists, which P2
+        // keeps in ascending order.  Only members with a non-zero third edge W[w][b] can
+        // contribute (a zero makes both terms vanish): row b of the NZ bitmap says which --
+        // typically a third of a clique, one contiguous stretch of the sorted list.  W[b][w]
+        // (= W[w][b], W is symmetric) and W[x][w] are row accesses with consecutive lanes on
+        // neighbouring columns: a few lines per edge instead of one row segment per member.
+        // Sums are exact integers: a 64-bit DPP reduction, applied by lane 0.  (The bitmap row
+        // of the wave's next edge is requested before the current edge is worked on.)
+        unsigned long long nz_nx = 0ull;
+        if (wv < nh && lane < nw) nz_nx = NZ[(unsigned)((int)(hl[wv] & 0xfffu) * nw + lane)];
+        for (int h = wv; h < nh; h += 4) {
+          const unsigned int it = hl[h];
+          const int rx = (int)(it >> 28);
+          const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
+          const unsigned long long nzw = nz_nx;
+          nz_nx = 0ull;
+          if (h + 4 < nh && lane < nw) nz_nx = NZ[(unsigned)((int)(hl[h + 4] & 0xfffu) * nw + lane)];
+          long long df = 0, dp = 0;
+#pragma unroll
+          for (int sg = 0; sg < 2; sg++) {
+            const unsigned short* L = sg == 0 ? ((rx == ROLE_A || rx == ROLE_FA) ? listB : listA) : (rx == ROLE_A ? listFb : listFa);
+            const int cnt = sg == 0 ? ((rx == ROLE_A || rx == ROLE_FA) ? nB : nA) : (rx == ROLE_A ? nFb : (rx == ROLE_B ? nFa : 0));
+            const bool perm = sg == 0 && merge && (rx == ROLE_A || rx == ROLE_B);
+            for (int p0 = 0; p0 < cnt; p0 += 128) {
+              // two passes of 64 members in flight
+              int w[2], ov[2], wb[2];
+              bool in[2];
+#pragma unroll
+              for (int c = 0; c < 2; c++) {
+                const int i = p0 + 64 * c + lane;
+                w[c] = i < cnt ? (int)L[i] : -1;
+                // bit w of the bitmap row: the word sits in lane w >> 6
+                const int wl = w[c] < 0 ? 0 : w[c] >> 6;
+                const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)nzw, wl, 64);
+                const unsigned int hi = (unsigned int)__shfl((int)(unsigned int)(nzw >> 32), wl, 64);
+                const unsigned long long word = ((unsigned long long)hi << 32) | lo;
+                in[c] = w[c] >= 0 && ((word >> (w[c] & 63)) & 1ull);
+                ov[c] = 0;
+                wb[c] = 0;
+              }
+              if (__ballot(in[0] || in[1]) == 0ull) continue;
+#pragma unroll
+              for (int c = 0; c < 2; c++)
+                if (in[c]) {
+                  wb[c] = Wm[(unsigned)(b * n + w[c])];
+                  ov[c] = Wm[(unsigned)(x * n + w[c])];
+                }
+#pragma unroll
+              for (int c = 0; c < 2; c++) {
+                // (lanes without a third edge hold 0,0: every term vanishes)
+                if (perm) {
+                  df += icf_term(W_PERM, wb[c]) - icf_term(ov[c], wb[c]);
+                  dp += icp_term(W_PERM, wb[c]) - icp_term(ov[c], wb[c]);
+                } else {
+                  df += icf_term(W_FORB, wb[c]) - icf_term(ov[c], wb[c]);
+                  dp += icp_term(W_FORB, wb[c]) - icp_term(ov[c], wb[c]);
+                }
+              }
+            }
+          }
+          df = wave_sum_i64(df);
+          dp = wave_sum_i64(dp);
+          if (lane == 0 && (df != 0 || dp != 0)) {
+            const unsigned ici = ic_index(x, b, n);
+            IcPair ic = IC[ici];
+            ic.f += df;
+            ic.p += dp;
+            IC[ici] = ic;
+            IC[ic_index(b, x, n)] = ic;
+#ifdef AHK_TIMING
+            atomicAdd(&s_chg, 1);
+#endif
+            const unsigned long long c1 = mkkey(ic.f, x, b), c2 = mkkey(ic.p, x, b);
+            fold_key(&bestF[x], c1);
+            fold_key(&bestP[x], c2);
+            fold_key(&bestF[b], c1);
+            fold_key(&bestP[b], c2);
+          }
+        }
+#endif
       }
       __syncthreads();
       AHK_T(3);
@@ -1161,7 +1424,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           }
         }
         if (tid < 4) s_cnt[tid] = 0;
-        if (tid == 0) s_items = 0;
+        if (tid == 0) { s_items = 0; s_nh = 0; }
         AHK_T(6);  // (diagnostic build: weight rewrites vs rescans)
         // rows whose maximum died: exact rescan now (they would tie the next argmax anyway)
         rescan_list(dlist, s_nd, wv, lane, n, nw, LV, IC, bestF, bestP);
