@@ -107,10 +107,10 @@ class CSynthSpec(C.Structure):
 
 # every symbol include/ahsoka_phase.h declares (tests check the library exports them all)
 ABI_SYMBOLS = [
-    "ahsoka_default_params", "ahsoka_backend_info", "ahsoka_abi_version", "ahsoka_phase_batch",
+    "ahsoka_default_params", "ahsoka_backend_info", "ahsoka_abi_version", "ahsoka_phase_batch", "ahsoka_phase_batch_multi",
     "ahsoka_result_free", "ahsoka_batch_upload", "ahsoka_phase_device", "ahsoka_batch_download",
     "ahsoka_batch_free", "ahsoka_batch_result_device", "ahsoka_batch_kernel_times", "ahsoka_batch_bytes", "ahsoka_render_chain",
-    "ahsoka_ingest", "ahsoka_ingest_dump", "ahsoka_batch_host_free", "ahsoka_synth_batch", "ahsoka_synth_write_text", "ahsoka_synth_truth",
+    "ahsoka_ingest", "ahsoka_ingest_dump", "ahsoka_batch_host_free", "ahsoka_synth_batch", "ahsoka_synth_select", "ahsoka_synth_shapes", "ahsoka_synth_write_text", "ahsoka_synth_truth",
     "ahsoka_test_introsort_u32", "ahsoka_test_detlog",
 ]
 
@@ -134,6 +134,8 @@ def lib() -> C.CDLL:
     L.ahsoka_phase_batch.argtypes = [C.POINTER(CChainBatch), C.POINTER(CPhaseParams), C.POINTER(CPhaseResult)]
     L.ahsoka_result_free.argtypes = [C.POINTER(CPhaseResult)]
     L.ahsoka_result_free.restype = None
+    L.ahsoka_phase_batch_multi.argtypes = [C.POINTER(CChainBatch), C.POINTER(CPhaseParams), i32p, C.c_int32,
+                                           C.POINTER(CPhaseResult)]
     L.ahsoka_batch_upload.argtypes = [C.POINTER(CChainBatch), C.POINTER(CPhaseParams), C.POINTER(C.c_void_p)]
     L.ahsoka_phase_device.argtypes = [C.c_void_p]
     L.ahsoka_batch_download.argtypes = [C.c_void_p, C.POINTER(CPhaseResult)]
@@ -150,6 +152,8 @@ def lib() -> C.CDLL:
     L.ahsoka_batch_host_free.argtypes = [C.POINTER(CChainBatch)]
     L.ahsoka_batch_host_free.restype = None
     L.ahsoka_synth_batch.argtypes = [C.POINTER(CSynthSpec), C.POINTER(C.POINTER(CChainBatch))]
+    L.ahsoka_synth_select.argtypes = [C.POINTER(CSynthSpec), i32p, C.c_int32, C.POINTER(C.POINTER(CChainBatch))]
+    L.ahsoka_synth_shapes.argtypes = [C.POINTER(CSynthSpec), i32p, i32p]
     L.ahsoka_synth_write_text.argtypes = [C.POINTER(CSynthSpec), C.c_char_p, C.c_char_p]
     L.ahsoka_synth_truth.argtypes = [C.POINTER(CSynthSpec), u8p, C.c_int64]
     L.ahsoka_synth_truth.restype = C.c_int64
@@ -302,6 +306,24 @@ def synth_batch(**kw) -> ChainBatch:
     return ChainBatch(cptr=out)
 
 
+def synth_select(chains, **kw) -> ChainBatch:
+    """The listed global chains of a synthetic workload (n_chains / first_chain of kw are ignored)."""
+    spec = synth_spec(**kw)
+    idx = np.ascontiguousarray(chains, dtype=np.int32)
+    out = C.POINTER(CChainBatch)()
+    _check(lib().ahsoka_synth_select(C.byref(spec), idx.ctypes.data_as(i32p), len(idx), C.byref(out)), "ahsoka_synth_select")
+    return ChainBatch(cptr=out)
+
+
+def synth_shapes(**kw):
+    """(n_bubbles, n_reads) of chains [first_chain, first_chain + n_chains) without generating them."""
+    spec = synth_spec(**kw)
+    nb = np.zeros(max(1, spec.n_chains), dtype=np.int32)
+    nr = np.zeros(max(1, spec.n_chains), dtype=np.int32)
+    _check(lib().ahsoka_synth_shapes(C.byref(spec), nb.ctypes.data_as(i32p), nr.ctypes.data_as(i32p)), "ahsoka_synth_shapes")
+    return nb[:spec.n_chains], nr[:spec.n_chains]
+
+
 def synth_truth(**kw) -> np.ndarray:
     """Truth alleles of the synthetic workload, flat: per chain [ploidy][B]."""
     spec = synth_spec(**kw)
@@ -398,6 +420,21 @@ def phase_batch(batch: ChainBatch, params: Optional[CPhaseParams] = None) -> Pha
     prm = params if params is not None else default_params()
     r = CPhaseResult()
     _check(lib().ahsoka_phase_batch(batch.ptr(), C.byref(prm), C.byref(r)), "ahsoka_phase_batch")
+    try:
+        return result_from_c(r)
+    finally:
+        lib().ahsoka_result_free(C.byref(r))
+
+
+def phase_batch_multi(batch: ChainBatch, devices, params: Optional[CPhaseParams] = None) -> PhaseResult:
+    """The hot path over several HIP devices of this node (ahsoka_phase_batch_multi): static
+    cost-weighted partition of the chains, one library-owned handle per device, results merged
+    into the batch's chain order."""
+    prm = params if params is not None else default_params()
+    dv = np.ascontiguousarray(devices, dtype=np.int32)
+    r = CPhaseResult()
+    _check(lib().ahsoka_phase_batch_multi(batch.ptr(), C.byref(prm), dv.ctypes.data_as(i32p), len(dv), C.byref(r)),
+           "ahsoka_phase_batch_multi")
     try:
         return result_from_c(r)
     finally:

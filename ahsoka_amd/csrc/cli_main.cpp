@@ -2,7 +2,8 @@
 // `Ahsoka only-bubbles -g <gfa> -o <prefix>`: the reference's command line
 // (src/polyassembly.cpp:39-57) over this repository's ingest and HIP path.
 // -t is accepted and ignored: chains are phased by the GPU, not by host threads
-// (the reference's -t>1 mode only handles ten chains, quirk Q16).
+// (the reference's -t>1 mode only handles ten chains, quirk Q16).  -d 0,1,.. (new)
+// shards the chains over several GPUs of the node (ahsoka_phase_batch_multi).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,7 +17,7 @@
 
 static void usage() {
   std::cerr << "Ahsoka [options] -g <graph.gfa> -a <alignments.gaf>\n"
-               "  Ahsoka phase -g <gfa> -a <gaf> -o <output prefix> [-t threads]\n"
+               "  Ahsoka phase -g <gfa> -a <gaf> -o <output prefix> [-t threads] [-d dev0,dev1,...]\n"
                "  Ahsoka only-bubbles -g <gfa> -o <output prefix>\n";
 }
 
@@ -55,12 +56,24 @@ int main(int argc, char** argv) {
   const std::string cmd = argv[1];
   if (cmd != "phase" && cmd != "only-bubbles") { usage(); return 1; }
   std::string gfa, gaf, prefix;
+  std::vector<int32_t> devices;
   for (int i = 2; i + 1 < argc; i += 2) {
     const std::string f = argv[i];
     if (f == "-g") gfa = argv[i + 1];
     else if (f == "-a") gaf = argv[i + 1];
     else if (f == "-o") prefix = argv[i + 1];
     else if (f == "-t" || f == "-s") { /* accepted, unused */ }
+    else if (f == "-d") {
+      std::stringstream ss(argv[i + 1]);
+      std::string tok;
+      while (std::getline(ss, tok, ',')) {
+        char* endp = nullptr;
+        const long v = std::strtol(tok.c_str(), &endp, 10);
+        if (tok.empty() || *endp || v < 0 || v > 1023) { usage(); return 1; }
+        devices.push_back((int32_t)v);
+      }
+      if (devices.empty()) { usage(); return 1; }
+    }
     else { usage(); return 1; }
   }
   if (gfa.empty() || prefix.empty() || (cmd == "phase" && gaf.empty())) { usage(); return 1; }
@@ -76,7 +89,8 @@ int main(int argc, char** argv) {
   ahsoka_phase_params prm;
   ahsoka_default_params(&prm);
   ahsoka_phase_result res;
-  rc = ahsoka_phase_batch(batch, &prm, &res);
+  if (devices.empty()) rc = ahsoka_phase_batch(batch, &prm, &res);
+  else rc = ahsoka_phase_batch_multi(batch, &prm, devices.data(), (int32_t)devices.size(), &res);
   if (rc) {
     std::cerr << "phasing failed (" << rc << "): this build has no CPU path, a HIP device is required\n";
     ahsoka_batch_host_free(batch);

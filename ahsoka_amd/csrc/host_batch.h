@@ -27,6 +27,9 @@ inline void ref_s1_order(int B, std::vector<int32_t>* out) {
 // single precision, compared as float.
 inline uint8_t ref_gt90_flag(float identity) { return (identity * 100) > 90 ? 1 : 0; }
 
+// structural checks of a caller-supplied batch (offsets monotone, indices in range); defined in phase_api.hip
+int validate_batch(const ahsoka_chain_batch* in);
+
 struct HostBatch {
   ahsoka_chain_batch view;  // MUST stay the first member (handle == &view)
   std::vector<int32_t> chain_id;

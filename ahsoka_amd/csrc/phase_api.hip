@@ -136,7 +136,7 @@ extern "C" int ahsoka_backend_info(char* buf, size_t buflen) {
   return AHSOKA_OK;
 }
 
-static int validate_batch(const ahsoka_chain_batch* in) {
+int ahk::validate_batch(const ahsoka_chain_batch* in) {
   if (!in || in->n_chains < 0) return AHSOKA_E_ARG;
   if (in->n_chains == 0) return AHSOKA_OK;
   if (!in->bubble_off || !in->allele_off || !in->apath_off || !in->node_off || !in->read_off || !in->rnode_off)
@@ -189,7 +189,7 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
                                    ahsoka_device_batch** handle) {
   if (!in || !prm || !handle) return AHSOKA_E_ARG;
   if (prm->ploidy < 2 || prm->ploidy > kMaxPloidy || prm->min_overlap < 0 || prm->max_slots < 0) return AHSOKA_E_ARG;
-  if (int e = validate_batch(in)) return e;
+  if (int e = ahk::validate_batch(in)) return e;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return AHSOKA_E_NODEVICE;
   if (prm->device < 0 || prm->device >= ndev) return AHSOKA_E_ARG;

@@ -12,6 +12,7 @@
 //
 // Every chain draws from its own splitmix64 stream seeded by (seed, chain
 // index), so a rank can generate exactly its shard of the global workload.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -112,17 +113,36 @@ int check_spec(const ahsoka_synth_spec* sp) {
 
 }  // namespace
 
-extern "C" int ahsoka_synth_batch(const ahsoka_synth_spec* sp, ahsoka_chain_batch** out) {
-  if (int e = check_spec(sp)) return e;
-  if (!out) return AHSOKA_E_ARG;
+namespace {
+
+// the chains `list` (global indices, any order) of the workload `sp` as one batch
+int build_batch(const ahsoka_synth_spec* sp, const std::vector<int64_t>& list, ahsoka_chain_batch** out) {
   ahk::HostBatch* hb = new (std::nothrow) ahk::HostBatch();
   if (!hb) return AHSOKA_E_NOMEM;
   try {
     // global node ids: chain ci's nodes follow those of chains 0..ci-1
+    int64_t maxc = -1;
+    for (int64_t ci : list) maxc = std::max(maxc, ci);
+    std::vector<int64_t> base_of;  // only for non-contiguous lists: node-id base of every chain up to maxc
     int64_t base = 0;
-    for (int64_t ci = 0; ci < sp->first_chain; ci++) {
-      SplitMix64 rng = chain_rng(sp->seed, ci);
-      base += 3 * (int64_t)chain_shape(*sp, rng).B + 1;
+    const bool contiguous = [&]() {
+      for (size_t i = 1; i < list.size(); i++)
+        if (list[i] != list[i - 1] + 1) return false;
+      return true;
+    }();
+    if (contiguous) {
+      for (int64_t ci = 0; ci < (list.empty() ? 0 : list[0]); ci++) {
+        SplitMix64 rng = chain_rng(sp->seed, ci);
+        base += 3 * (int64_t)chain_shape(*sp, rng).B + 1;
+      }
+    } else {
+      base_of.resize((size_t)maxc + 1);
+      int64_t acc = 0;
+      for (int64_t ci = 0; ci <= maxc; ci++) {
+        base_of[(size_t)ci] = acc;
+        SplitMix64 rng = chain_rng(sp->seed, ci);
+        acc += 3 * (int64_t)chain_shape(*sp, rng).B + 1;
+      }
     }
     hb->bubble_off.push_back(0);
     hb->allele_off.push_back(0);
@@ -132,8 +152,8 @@ extern "C" int ahsoka_synth_batch(const ahsoka_synth_spec* sp, ahsoka_chain_batc
     hb->rnode_off.push_back(0);
     hb->has_genotype = sp->ploidy != 2;
     SynthChain ch;
-    for (int c = 0; c < sp->n_chains; c++) {
-      int64_t ci = (int64_t)sp->first_chain + c;
+    for (int64_t ci : list) {
+      if (!contiguous) base = base_of[(size_t)ci];
       make_chain(*sp, ci, ch);
       hb->chain_id.push_back((int32_t)ci);
       for (int k = 0; k < ch.B; k++) {
@@ -173,6 +193,42 @@ extern "C" int ahsoka_synth_batch(const ahsoka_synth_spec* sp, ahsoka_chain_batc
     return AHSOKA_E_NOMEM;
   }
   *out = &hb->view;
+  return AHSOKA_OK;
+}
+
+}  // namespace
+
+extern "C" int ahsoka_synth_batch(const ahsoka_synth_spec* sp, ahsoka_chain_batch** out) {
+  if (int e = check_spec(sp)) return e;
+  if (!out) return AHSOKA_E_ARG;
+  std::vector<int64_t> list((size_t)sp->n_chains);
+  for (int c = 0; c < sp->n_chains; c++) list[(size_t)c] = (int64_t)sp->first_chain + c;
+  return build_batch(sp, list, out);
+}
+
+// chains picked by global index (a rank's shard of a cost-weighted partition is not a range)
+extern "C" int ahsoka_synth_select(const ahsoka_synth_spec* sp, const int32_t* chains, int32_t n, ahsoka_chain_batch** out) {
+  if (int e = check_spec(sp)) return e;
+  if (!out || n < 0 || (n > 0 && !chains)) return AHSOKA_E_ARG;
+  std::vector<int64_t> list((size_t)n);
+  for (int i = 0; i < n; i++) {
+    if (chains[i] < 0) return AHSOKA_E_ARG;
+    list[(size_t)i] = chains[i];
+  }
+  return build_batch(sp, list, out);
+}
+
+// bubbles and reads of every chain of the workload, without generating it (every rank can
+// compute the same cost-weighted partition from this, without communication)
+extern "C" int ahsoka_synth_shapes(const ahsoka_synth_spec* sp, int32_t* n_bubbles, int32_t* n_reads) {
+  if (int e = check_spec(sp)) return e;
+  if (!n_bubbles || !n_reads) return AHSOKA_E_ARG;
+  for (int c = 0; c < sp->n_chains; c++) {
+    SplitMix64 rng = chain_rng(sp->seed, (int64_t)sp->first_chain + c);
+    const ChainShape shp = chain_shape(*sp, rng);
+    n_bubbles[c] = shp.B;
+    n_reads[c] = shp.R;
+  }
   return AHSOKA_OK;
 }
 

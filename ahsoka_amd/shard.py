@@ -223,3 +223,46 @@ def decode_block(block: np.ndarray, bubble_off: np.ndarray, ploidy: int):
     for i in range(ploidy):
         hap[base_out + i * Prep + col] = hap_raw[base_in + i * Prep + col]
     return status, pos_off, pos, hap
+
+
+def plan_partition(n_bubbles: np.ndarray, n_reads: np.ndarray, world: int, equal_shapes: bool) -> Tuple[str, List[np.ndarray]]:
+    """The static partition every rank computes for itself from the workload's shapes (no
+    communication): contiguous blocks when all chains have the same shape, the cost-weighted
+    LPT partition otherwise.  Returns (name, per rank the ascending global chain indices)."""
+    n = len(n_bubbles)
+    if equal_shapes or world == 1:
+        return "block", [np.arange(f, f + c) for f, c in block_partition(n, world)]
+    return "lpt", lpt_partition(chain_cost(np.asarray(n_reads), np.asarray(n_bubbles)), world)
+
+
+def block_length(n_bubbles_of_shard: np.ndarray, ploidy: int) -> int:
+    """int32 length of a shard's packed result block [status | npos | pos | hap]"""
+    return 2 * len(n_bubbles_of_shard) + (1 + ploidy) * int(np.sum(n_bubbles_of_shard))
+
+
+def decode_gathered(blocks: Sequence[np.ndarray], owned: Sequence[np.ndarray], n_bubbles: np.ndarray, ploidy: int):
+    """Rank 0, after the gather: every rank's (padded) block back into ONE result in global
+    chain order -> (status, pos_off, pos, hap_allele) like PhaseResult.  ``owned[r]`` are the
+    global indices of rank r's chains in the order of its block; shards must tile the list."""
+    n = len(n_bubbles)
+    status = np.full(n, -1, dtype=np.int32)
+    npos = np.zeros(n, dtype=np.int64)
+    parts = []
+    for r, blk in enumerate(blocks):
+        nb = np.asarray(n_bubbles)[owned[r]]
+        boff = np.concatenate([[0], np.cumsum(nb)]).astype(np.int64)
+        st, pos_off, pos, hap = decode_block(np.asarray(blk)[: block_length(nb, ploidy)], boff, ploidy)
+        status[owned[r]] = st
+        npos[owned[r]] = np.diff(pos_off)
+        parts.append((pos_off, pos, hap))
+    if (status < 0).any():
+        raise ValueError("the shards do not tile the chain list")
+    pos_off = np.concatenate([[0], np.cumsum(npos)]).astype(np.int64)
+    pos = np.zeros(int(pos_off[-1]), dtype=np.int32)
+    hap = np.zeros(ploidy * int(pos_off[-1]), dtype=np.int32)
+    for r, (po, ps, hp) in enumerate(parts):
+        for j, c in enumerate(owned[r]):
+            a, b = int(po[j]), int(po[j + 1])
+            pos[pos_off[c]:pos_off[c + 1]] = ps[a:b]
+            hap[ploidy * pos_off[c]:ploidy * pos_off[c + 1]] = hp[ploidy * a:ploidy * b]
+    return status, pos_off, pos, hap

@@ -4,19 +4,29 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (k_readset + k_phase, then the result
-download and, for N > 1, the single gather to rank 0) over one synthetic batch
-whose inputs are already resident in HBM.  Workload at every N: BASELINE.json
-configs[2] -- 10k chains x 50 bubbles x 1000 reads/chain, ploidy 2 -- PER GPU
-(weak scaling: rank r generates chains [r*10k, (r+1)*10k) of one global
-deterministic workload; no data-path collective).
+A "step" is one pass of the hot path (k_readset + k_phase, then the results to
+host memory: the download at N = 1, the single gather of every rank's packed
+result block to rank 0 plus its copy to the host for N > 1) over one synthetic
+batch whose inputs are already resident in HBM.
+
+Workload: BASELINE.json configs[2] -- 10 000 chains x 50 bubbles x 1000
+reads/chain, ploidy 2.  For N > 1 the default is what BASELINE.json states:
+that FIXED workload sharded over the N GPUs (strong scaling; `value` and
+`"scaling": "strong"`), one process per GPU, static partition, no data-path
+collective, one RCCL gather at the end of the step; the same run also measures
+the weak form (10 000 chains per GPU) and reports it as a second figure
+(`"weak"`).  `--scaling weak` makes the weak form the headline instead.
+Chains of equal shape (configs 1-4) are split into contiguous blocks; the
+power-law config 5 (`--config c5`) is split by the cost-weighted LPT partition
+(shard.lpt_partition over shard.chain_cost), which every rank computes for
+itself from the workload's shapes.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline      dominant kernel (k_phase): algorithmic bytes / its mean HIP-event
                 duration on the launch stream, against 8 TB/s HBM
   cpu_baseline  the CPU oracle ("port": oracle/oracle.cpp, NOT the upstream
                 binary, which cannot be built here) on a bounded sample of the
-                same workload, timed on this box's host cores.
+                same workload, timed on this box's host cores (N = 1 only).
 """
 import argparse
 import json
@@ -32,13 +42,53 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+class Shard:
+    """This rank's share of one global synthetic workload, resident in HBM."""
+
+    def __init__(self, capi, shard, cfg, total_chains, rank, world, device_index, max_slots=0):
+        self.capi, self.shardmod = capi, shard
+        self.cfg = dict(cfg)
+        self.cfg["n_chains"] = total_chains
+        self.cfg["first_chain"] = 0
+        self.total = total_chains
+        self.ploidy = cfg["ploidy"]
+        self.world, self.rank = world, rank
+        # every rank derives the same partition from the workload's shapes: no communication
+        self.nb, self.nr = capi.synth_shapes(**self.cfg)
+        self.partition, self.owned = shard.plan_partition(self.nb, self.nr, world, cfg.get("b_mode", 0) == 0)
+        mine = self.owned[rank]
+        t0 = time.time()
+        if self.partition == "block":
+            c = dict(self.cfg)
+            c["n_chains"] = len(mine)
+            c["first_chain"] = int(mine[0]) if len(mine) else 0
+            self.batch = capi.synth_batch(**c)
+        else:
+            self.batch = capi.synth_select(mine, **self.cfg)
+        self.synth_s = time.time() - t0
+        self.bubble_off = self.batch.arrays()["bubble_off"]
+        self.prm = capi.default_params(ploidy=self.ploidy, device=device_index, max_slots=max_slots)
+        t0 = time.time()
+        self.dev = capi.DeviceBatch(self.batch, self.prm)
+        self.upload_s = time.time() - t0
+        # length of every rank's packed result block [status | npos | pos | hap]: 2C + (1+p) * sum B
+        self.block_len = [shard.block_length(self.nb[o], self.ploidy) for o in self.owned]
+        self.max_block = max(self.block_len)
+
+    def free(self):
+        self.dev.free()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", help="BASELINE config (c3 = headline); others for experiments")
-    ap.add_argument("--chains", type=int, default=0, help="override chains per GPU (experiments only)")
+    ap.add_argument("--chains", type=int, default=0, help="override the workload's chain count (experiments only)")
+    ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
+                    help="N > 1: strong = the fixed workload split over the ranks (default), weak = that workload per rank")
+    ap.add_argument("--max-slots", type=int, default=0, help="ahsoka_phase_params.max_slots (experiments only)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="chains timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
@@ -70,79 +120,104 @@ def main():
             dist.init_process_group(backend)
 
     cfg = dict(capi.CONFIGS[args.config])
-    per_gpu = args.chains if args.chains > 0 else cfg["n_chains"]
-    cfg["n_chains"] = per_gpu
-    cfg["first_chain"] = rank * per_gpu
-    ploidy = cfg["ploidy"]
-    t_gen = time.time()
-    batch = capi.synth_batch(**cfg)
-    t_gen = time.time() - t_gen
-    arr = batch.arrays()
-    bubble_off = arr["bubble_off"]
-    max_pos = int(np.diff(bubble_off).max())
-    prm = capi.default_params(ploidy=ploidy, device=local_rank)
-
-    # host buffers -> HBM once; the timed region starts with inputs resident
-    t_up = time.time()
-    dev = capi.DeviceBatch(batch, prm)
-    t_up = time.time() - t_up
-    owned = np.arange(rank * per_gpu, (rank + 1) * per_gpu)
-
-    def step():
-        dev.phase()
-        res = dev.download()
-        gathered = None
-        if world > 1:
-            # the one collective of the path: every rank's packed result block
-            # (device memory, fixed layout) to rank 0 -- RCCL gather over xGMI
-            # (.clone(): the collective then works on memory torch itself allocated; the
-            # library's block lives in the system HIP runtime's allocation table)
-            block = dev.result_tensor()
-            gathered = shard.gather_device_blocks(block.clone() if backend == "nccl" else block.cpu())
-        return res, gathered
+    base_chains = args.chains if args.chains > 0 else cfg["n_chains"]
+    scaling = args.scaling if args.scaling != "auto" else "strong"
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    k_phase_ms, k_readset_ms = [], []
-    fence()
-    t0 = time.perf_counter()
-    res = None
-    for _ in range(args.steps):
-        res, gathered = step()
-        kt = dev.kernel_times_ms()
-        k_phase_ms.append(kt["k_phase"])
-        k_readset_ms.append(kt["k_readset"])
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run(total_chains, steps, warmup):
+        """-> dict of measurements of `steps` timed steps on the workload of total_chains chains"""
+        sh = Shard(capi, shard, cfg, total_chains, rank, world, local_rank, args.max_slots)
+        pad = None
+        if world > 1:
+            pad = torch.full((sh.max_block,), -1, dtype=torch.int32, device=coll_device)
 
-    phased = res.phased_bubbles(bubble_off)
-    if world > 1:
-        t = torch.tensor([phased], dtype=torch.int64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total_phased = int(t.item())
-    else:
-        total_phased = phased
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = total_phased / (elapsed / args.steps)
+        def step():
+            sh.dev.phase()
+            if world == 1:
+                return sh.dev.download(), None
+            # the one collective of the path: every rank's packed result block (device memory,
+            # layout fixed by the shard's shape, padded to the longest) to rank 0 -- one RCCL
+            # gather over xGMI -- and from there to the host
+            block = sh.dev.result_tensor()
+            pad[: block.numel()].copy_(block if backend == "nccl" else block.cpu())
+            bufs = shard.gather_device_blocks(pad)
+            host = torch.stack(bufs).cpu().numpy() if rank == 0 else None
+            return None, host
+
+        for _ in range(warmup):
+            step()
+        k_phase_ms, k_readset_ms = [], []
+        fence()
+        t0 = time.perf_counter()
+        res = host = None
+        for _ in range(steps):
+            res, host = step()
+            kt = sh.dev.kernel_times_ms()
+            k_phase_ms.append(kt["k_phase"])
+            k_readset_ms.append(kt["k_readset"])
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        out = {"elapsed": elapsed, "steps": steps, "k_phase_ms": float(np.mean(k_phase_ms)),
+               "k_readset_ms": float(np.mean(k_readset_ms)), "shard": sh}
+        if rank == 0:
+            if world == 1:
+                out["phased"] = res.phased_bubbles(sh.bubble_off)
+                out["P_total"] = int(res.pos_off[-1])
+                out["n_phased"] = int((res.status == capi.ST_PHASED).sum())
+                out["verified"] = None
+            else:
+                # outside the timed region: decode every rank's block into the global chain
+                # order and check rank 0's own shard against the library's download path
+                status, pos_off, pos, hap = shard.decode_gathered(host, sh.owned, sh.nb, sh.ploidy)
+                out["phased"] = int(sh.nb[status == capi.ST_PHASED].sum())
+                out["P_total"] = int(pos_off[-1])
+                out["n_phased"] = int((status == capi.ST_PHASED).sum())
+                own = sh.dev.download()
+                mine = sh.owned[0]
+                ok = bool((status[mine] == own.status).all() and (np.diff(pos_off)[mine] == np.diff(own.pos_off)).all())
+                for j in (0, len(mine) // 2, len(mine) - 1):  # spot-check alleles of three of rank 0's chains
+                    if len(mine) == 0:
+                        break
+                    c = int(mine[j])
+                    ok = ok and bool((hap[sh.ploidy * pos_off[c]:sh.ploidy * pos_off[c + 1]]
+                                      == own.hap_allele[sh.ploidy * own.pos_off[j]:sh.ploidy * own.pos_off[j + 1]]).all())
+                out["verified"] = ok
+                assert out["verified"], "gathered block of rank 0 differs from its download"
+        return out
+
+    total_main = base_chains * (world if scaling == "weak" else 1)
+    m = run(total_main, args.steps, args.warmup)
+    second = None
+    if world > 1 and args.scaling == "auto":
+        m["shard"].free()
+        second = run(base_chains * world, max(1, args.steps // 2), min(1, args.warmup))
 
     if rank == 0:
-        # algorithmic bytes of one launch: inputs once + outputs once
-        P_total = int(res.pos_off[-1])
-        n_phased = int((res.status == capi.ST_PHASED).sum())
-        alg_bytes = batch.algorithmic_input_bytes(ploidy) + 4 * (P_total + ploidy * P_total + n_phased)
-        kp = float(np.mean(k_phase_ms))
+        sh = m["shard"]
+        ploidy = sh.ploidy
+        ms_per_step = m["elapsed"] * 1e3 / m["steps"]
+        value = m["phased"] / (m["elapsed"] / m["steps"])
+        # algorithmic bytes of one launch on rank 0 (SURVEY.md 8.d4): inputs once + outputs once
+        if world == 1:
+            alg_bytes = sh.batch.algorithmic_input_bytes(ploidy) + 4 * (m["P_total"] + ploidy * m["P_total"] + m["n_phased"])
+        else:
+            own = sh.dev.download()
+            Pt = int(own.pos_off[-1])
+            alg_bytes = sh.batch.algorithmic_input_bytes(ploidy) + 4 * (Pt + ploidy * Pt + int((own.status == capi.ST_PHASED).sum()))
+        kp = m["k_phase_ms"]
         achieved = alg_bytes / (kp * 1e-3) / 1e9
-        traffic = pmc_traffic(args.config, per_gpu)
+        traffic = pmc_traffic(args.config, len(sh.owned[0]))
         stream = stream_copy_gbps(torch, device)
+        shape = (f"{cfg['n_bubbles']} bubbles x {cfg['n_reads']} reads/chain" if cfg.get("b_mode", 0) == 0
+                 else "power-law bubble counts (1..500), ~40x read depth")
         out = {
             "metric": "bubbles/s phased (ploidy 2, 1000 reads/chain)",
             "value": value,
@@ -152,16 +227,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "int64",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[2]: {per_gpu} chains x {cfg['n_bubbles']} bubbles x "
-                            f"{cfg['n_reads']} reads/chain, ploidy {ploidy}, per GPU",
+                "workload": f"BASELINE configs[{int(args.config[1:]) - 1}]: {sh.total} chains x {shape}, ploidy {ploidy}"
+                            + (f", sharded over {world} GPUs" if world > 1 else ""),
                 "config_name": args.config,
-                "chains_per_gpu": per_gpu,
-                "parallelism": f"chain-shard x{world}, one gather",
+                "chains_total": sh.total,
+                "chains_rank0": len(sh.owned[0]),
+                "parallelism": f"chain-shard x{world} ({sh.partition} partition), one gather",
             },
             "roofline": {
                 "bound": "hbm",
@@ -173,22 +249,34 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": kp,
-                "k_readset_ms": float(np.mean(k_readset_ms)),
+                "k_readset_ms": m["k_readset_ms"],
                 # the measured traffic (committed PMC summary of this workload) over this run's kernel
                 # time, against the nominal peak and against a streaming copy measured in this job
                 "traffic_rate_GBps": (traffic / (kp * 1e-3) / 1e9) if traffic else None,
                 "stream_copy_GBps": stream,
             },
-            "phased_bubbles_per_step": total_phased,
-            "phased_chains_rank0": n_phased,
-            "upload_s": t_up,
-            "synth_s": t_gen,
+            "phased_bubbles_per_step": m["phased"],
+            "phased_chains": m["n_phased"],
+            "gather_verified": m["verified"],
+            "upload_s": sh.upload_s,
+            "synth_s": sh.synth_s,
             "backend": capi.backend_info(),
         }
+        if second is not None:
+            out["weak"] = {
+                "value": second["phased"] / (second["elapsed"] / second["steps"]),
+                "unit": "bubbles/s",
+                "ms_per_step": second["elapsed"] * 1e3 / second["steps"],
+                "steps": second["steps"],
+                "chains_per_gpu": base_chains,
+                "phased_bubbles_per_step": second["phased"],
+                "k_phase_ms_rank0": second["k_phase_ms"],
+            }
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(cfg, prm, args.cpu_sample)
+            c1 = dict(cfg)
+            out["cpu_baseline"] = cpu_baseline(c1, sh.prm, args.cpu_sample)
         print(json.dumps(out), flush=True)
-    dev.free()
+    (second or m)["shard"].free()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -184,6 +184,19 @@ int ahsoka_phase_batch(const ahsoka_chain_batch* in, const ahsoka_phase_params* 
 void ahsoka_result_free(ahsoka_phase_result* out);
 
 /*
+ * The same call over several HIP devices of one node (SURVEY.md 8.b2 "device list";
+ * the reference's own attempt at parallelism is the two-thread split of
+ * src/polyassembly.cpp:190-215).  Chains are independent, so they are split by a static
+ * cost-weighted partition (longest processing time first), phased concurrently -- one
+ * host thread, device handle and HIP stream per entry of `devices`, all owned by the
+ * library, no data-path collective -- and merged back into the caller's chain order:
+ * the result is bit-identical to ahsoka_phase_batch whatever the device list.
+ * An ordinal may repeat ({0,0}: two shards on one GPU).  prm->device is ignored.
+ */
+int ahsoka_phase_batch_multi(const ahsoka_chain_batch* in, const ahsoka_phase_params* prm,
+                             const int32_t* devices, int32_t n_devices, ahsoka_phase_result* out);
+
+/*
  * Device-resident variant used by the benchmark: upload once, phase many
  * times (the timed region starts with inputs already in HBM), download once.
  */
@@ -250,6 +263,11 @@ typedef struct ahsoka_synth_spec {
                           global workload: rank sharding without communication */
 } ahsoka_synth_spec;
 int ahsoka_synth_batch(const ahsoka_synth_spec* spec, ahsoka_chain_batch** out);
+/* chains picked by global index instead of a range (a shard of a cost-weighted partition) */
+int ahsoka_synth_select(const ahsoka_synth_spec* spec, const int32_t* chains, int32_t n,
+                        ahsoka_chain_batch** out);
+/* bubbles / reads of chains [first_chain, first_chain+n_chains) without generating them */
+int ahsoka_synth_shapes(const ahsoka_synth_spec* spec, int32_t* n_bubbles, int32_t* n_reads);
 int ahsoka_synth_write_text(const ahsoka_synth_spec* spec, const char* gfa_path,
                             const char* gaf_path);
 /* truth haplotypes the reads were drawn from: per chain ploidy rows of B alleles,

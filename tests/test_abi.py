@@ -47,6 +47,20 @@ def test_argument_errors():
         capi.ingest("/nonexistent.gfa", "/nonexistent.gaf")
 
 
+def test_multi_device_entry_argument_errors():
+    import numpy as np
+
+    L = capi.lib()
+    b = capi.synth_batch(**capi.CONFIGS["c1"])
+    prm = capi.default_params()
+    r = capi.CPhaseResult()
+    dv = np.zeros(2, dtype=np.int32)
+    assert L.ahsoka_phase_batch_multi(b.ptr(), C.byref(prm), dv.ctypes.data_as(capi.i32p), 0, C.byref(r)) == capi.E_ARG
+    assert L.ahsoka_phase_batch_multi(b.ptr(), C.byref(prm), None, 2, C.byref(r)) == capi.E_ARG
+    neg = np.array([0, -1], dtype=np.int32)
+    assert L.ahsoka_phase_batch_multi(b.ptr(), C.byref(prm), neg.ctypes.data_as(capi.i32p), 2, C.byref(r)) == capi.E_ARG
+
+
 def test_no_cpu_fallback_without_device():
     import torch
 
@@ -55,6 +69,9 @@ def test_no_cpu_fallback_without_device():
     b = capi.synth_batch(**capi.CONFIGS["c1"])
     with pytest.raises(capi.AhsokaError) as e:
         capi.phase_batch(b)
+    assert e.value.code == capi.E_NODEVICE
+    with pytest.raises(capi.AhsokaError) as e:
+        capi.phase_batch_multi(b, [0, 1])
     assert e.value.code == capi.E_NODEVICE
     assert capi.backend_info() == "hip:no-device"
 

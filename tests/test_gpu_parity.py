@@ -423,10 +423,44 @@ def test_cli_end_to_end(tmp_path):
     g = capi.phase_batch(b)
     expect = "".join(capi.render_chain(b, g, c) for c in range(b.n_chains))
     assert open(prefix + "-result.txt").read() == expect
+    # -d 0,0: the chains sharded over a device list (here: twice the same GPU), same text
+    prefix2 = str(tmp_path / "out2")
+    subprocess.run([exe, "phase", "-g", os.path.join(gold, "c1.gfa"), "-a", os.path.join(gold, "c1.gaf"), "-o", prefix2,
+                    "-d", "0,0"], check=True, capture_output=True)
+    assert open(prefix2 + "-result.txt").read() == expect
     assert open(prefix + "-bubbleinfo.txt").read().startswith("chain id: 0size: 5\nbubble id: 0\nnode id: 160,158,159,157,\n")
     # per-chain files hold the node lines only (src/alignmentstoreadset.cpp:411-412,449,456)
     lines = open(prefix + "-chain9-result.txt").read().split("\n")
     assert len(lines) == 3 and lines[0].endswith("),") and lines[2] == ""
+
+
+def test_multi_device_entry_equals_single_device():
+    """ahsoka_phase_batch_multi: chains split by cost over a device list, one library-owned
+    handle per entry, results merged into the batch order.  With one GPU the list {0,0} /
+    {0,0,0} runs the shards side by side on it: every field, stage dumps included, must
+    equal the single-device call bit for bit (and with it the oracle)."""
+    cfg = dict(capi.CONFIGS["c5"])
+    cfg["n_chains"] = 700
+    cfg["first_chain"] = 18000          # a stretch with one 142-bubble chain: skewed costs
+    b = capi.synth_batch(**cfg)
+    prm = capi.default_params(want_stages=1)
+    one = capi.phase_batch(b, prm)
+    for devs in ([0, 0], [0, 0, 0]):
+        m = capi.phase_batch_multi(b, devs, prm)
+        for k in ("status", "pos_off", "pos", "hap_allele", "hap_cluster", "n_reads", "n_clusters", "n_iterations"):
+            np.testing.assert_array_equal(getattr(m, k), getattr(one, k), err_msg=k)
+        for k in ("vmat_off", "vfull", "vpart", "fread_off", "fread_name", "fread_cluster", "score_off", "score_q"):
+            np.testing.assert_array_equal(m.stages[k], one.stages[k], err_msg=k)
+    o = ob.phase_batch(b, prm, n_threads=16)
+    np.testing.assert_array_equal(one.hap_allele, o.hap_allele)
+    # ploidy 4 (genotype array travels with the shards), no stages
+    b4 = capi.synth_batch(n_chains=9, n_bubbles=12, n_reads=240, ploidy=4, seed=0xA450CA04)
+    p4 = capi.default_params(ploidy=4)
+    np.testing.assert_array_equal(capi.phase_batch_multi(b4, [0, 0], p4).hap_allele, capi.phase_batch(b4, p4).hap_allele)
+    # a single entry is the plain call on that device; an unknown ordinal is an argument error
+    np.testing.assert_array_equal(capi.phase_batch_multi(b, [0], prm).hap_allele, one.hap_allele)
+    with pytest.raises(capi.AhsokaError):
+        capi.phase_batch_multi(b, [0, 4096], prm)
 
 
 def test_degenerate_batches():

@@ -74,6 +74,75 @@ def _worker_blocks(rank, world, port, cfg, q):
     dist.destroy_process_group()
 
 
+def _worker_lpt(rank, world, port, cfg, q):
+    """the N > 1 step for skewed chains: every rank computes the same LPT partition from the
+    workload's shapes, generates exactly its (non-contiguous) chains, phases them, and the
+    padded packed blocks meet on rank 0 in ONE gather; rank 0 restores the global order"""
+    import torch
+    import torch.distributed as dist
+
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ahsoka_amd import capi, shard
+    import oracle_binding as ob
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nb, nr = capi.synth_shapes(**cfg)
+    name, owned = shard.plan_partition(nb, nr, world, cfg["b_mode"] == 0)
+    mine = owned[rank]
+    b = capi.synth_select(mine, **cfg) if name == "lpt" else capi.synth_batch(**dict(cfg, n_chains=len(mine), first_chain=int(mine[0])))
+    res = ob.phase_batch(b, capi.default_params(ploidy=cfg["ploidy"]))
+    blk = shard.pack_block(res, b.arrays()["bubble_off"])
+    maxlen = max(shard.block_length(nb[o], cfg["ploidy"]) for o in owned)
+    pad = torch.full((maxlen,), -1, dtype=torch.int32)
+    pad[: len(blk)] = torch.from_numpy(blk)
+    bufs = shard.gather_device_blocks(pad)
+    if rank == 0:
+        q.put((name, [o.tolist() for o in owned], shard.decode_gathered([x.numpy() for x in bufs], owned, nb, cfg["ploidy"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["lpt_c5", "strong_block"])
+def test_two_ranks_partition_end_to_end(mode):
+    """config 5's cost-weighted partition (non-contiguous ownership -> global order) and the
+    strong-scaling split of a fixed workload with unequal blocks, world_size 2 over gloo"""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ahsoka_amd import capi
+    import oracle_binding as ob
+
+    if mode == "lpt_c5":
+        cfg = dict(capi.CONFIGS["c5"], n_chains=61, first_chain=0)
+        cfg["seed"] = 0xA450CA05
+    else:
+        cfg = dict(n_chains=9, n_bubbles=6, n_reads=60, ploidy=2, b_mode=0, mean_span=7.0, seed=79, first_chain=0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + (7 if mode == "lpt_c5" else 0)
+    procs = [ctx.Process(target=_worker_lpt, args=(r, 2, port, cfg, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    name, owned, (status, pos_off, pos, hap) = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = ob.phase_batch(capi.synth_batch(**cfg), capi.default_params())
+    np.testing.assert_array_equal(status, ref.status)
+    np.testing.assert_array_equal(pos_off, ref.pos_off)
+    np.testing.assert_array_equal(pos, ref.pos)
+    np.testing.assert_array_equal(hap, ref.hap_allele)
+    if mode == "lpt_c5":
+        assert name == "lpt" and sorted(owned[0] + owned[1]) == list(range(61))
+        assert any(b != a + 1 for o in owned for a, b in zip(o, o[1:]))  # ownership is not a range
+    else:
+        assert name == "block" and len(owned[0]) == 5 and len(owned[1]) == 4  # unequal blocks, padded gather
+
+
 def test_two_ranks_block_gather():
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
