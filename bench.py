@@ -173,6 +173,7 @@ def main():
                 out["P_total"] = int(res.pos_off[-1])
                 out["n_phased"] = int((res.status == capi.ST_PHASED).sum())
                 out["verified"] = None
+                own = res
             else:
                 # outside the timed region: decode every rank's block into the global chain
                 # order and check rank 0's own shard against the library's download path
@@ -191,6 +192,10 @@ def main():
                                       == own.hap_allele[sh.ploidy * own.pos_off[j]:sh.ploidy * own.pos_off[j + 1]]).all())
                 out["verified"] = ok
                 assert out["verified"], "gathered block of rank 0 differs from its download"
+            # algorithmic bytes of one launch on rank 0: inputs once + outputs once
+            Pt = int(own.pos_off[-1])
+            out["alg_bytes"] = sh.batch.algorithmic_input_bytes(sh.ploidy) + 4 * (
+                Pt + sh.ploidy * Pt + int((own.status == capi.ST_PHASED).sum()))
         return out
 
     total_main = base_chains * (world if scaling == "weak" else 1)
@@ -205,13 +210,7 @@ def main():
         ploidy = sh.ploidy
         ms_per_step = m["elapsed"] * 1e3 / m["steps"]
         value = m["phased"] / (m["elapsed"] / m["steps"])
-        # algorithmic bytes of one launch on rank 0: inputs once + outputs once
-        if world == 1:
-            alg_bytes = sh.batch.algorithmic_input_bytes(ploidy) + 4 * (m["P_total"] + ploidy * m["P_total"] + m["n_phased"])
-        else:
-            own = sh.dev.download()
-            Pt = int(own.pos_off[-1])
-            alg_bytes = sh.batch.algorithmic_input_bytes(ploidy) + 4 * (Pt + ploidy * Pt + int((own.status == capi.ST_PHASED).sum()))
+        alg_bytes = m["alg_bytes"]
         kp = m["k_phase_ms"]
         achieved = alg_bytes / (kp * 1e-3) / 1e9
         traffic = pmc_traffic(args.config, len(sh.owned[0]))
