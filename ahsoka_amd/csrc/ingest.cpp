@@ -259,8 +259,43 @@ struct Graph {
     }
   }
 
-  // allele paths of a bubble with != 2 inner nodes: depth-first from the sink
+  // Allele paths of a bubble with != 2 inner nodes: depth-first from the sink, children in
+  // link order (src/chainstoreadset.cpp:44-116).  The listing is exponential in the number of
+  // stacked sub-bubbles (2^k paths), and the reference walks all of it.  Here the number of
+  // paths is first COUNTED with a memo per (node, direction) -- linear in the bubble's links --
+  // and the walk itself stops after kMaxAllelePaths paths: a bubble with more alleles than the
+  // device handles (16, phase_kernels.h) makes its chain AHSOKA_ST_UNSUPPORTED anyway, so the
+  // hot path never sees a truncated list as if it were complete.  Up to the bound the listing
+  // is the reference's, path for path, in order (tests/golden/sbub.ref.txt).
+  static constexpr size_t kMaxAllelePaths = 1024;
+
+  size_t count_paths(const GBubble& b, int nid, int dirflag, std::unordered_map<long long, size_t>* memo,
+                     std::unordered_set<int>* onwalk) {
+    const long long key = ((long long)nid << 1) | (dirflag ? 1 : 0);
+    auto it = memo->find(key);
+    if (it != memo->end()) return it->second;
+    if (onwalk->count(nid)) return kMaxAllelePaths + 1;  // a cycle: the walk's revisit rule decides, no closed form
+    const GNode& nd = nodes[nid];
+    const std::vector<Link>& next = (dirflag == 0) ? nd.out_minus : nd.out_plus;
+    bool within = true;
+    for (const Link& ch : next)
+      if (!b.has(ch.to)) within = false;
+    size_t cnt = 1;
+    if (!next.empty() && within) {
+      cnt = 0;
+      onwalk->insert(nid);
+      for (const Link& ch : next) {
+        cnt += count_paths(b, ch.to, ch.plus, memo, onwalk);
+        if (cnt > kMaxAllelePaths) { cnt = kMaxAllelePaths + 1; break; }
+      }
+      onwalk->erase(nid);
+    }
+    (*memo)[key] = cnt;
+    return cnt;
+  }
+
   void dfs_paths(const GBubble& b, int nid, int dirflag, std::vector<int>* seq, std::vector<std::vector<int>>* out) {
+    if (out->size() >= kMaxAllelePaths) return;
     if (std::find(seq->begin(), seq->end(), nid) == seq->end()) seq->push_back(nid);
     const GNode& nd = nodes[nid];
     const std::vector<Link>& next = (dirflag == 0) ? nd.out_minus : nd.out_plus;
@@ -288,6 +323,12 @@ struct Graph {
     for (const Link& ch : nodes[b.sink].out_minus)
       if (!b.has(ch.to)) minus_within = false;
     const int dirflag = minus_within ? 0 : 1;
+    {
+      std::unordered_map<long long, size_t> memo;
+      std::unordered_set<int> onwalk;
+      const size_t cnt = count_paths(b, b.sink, dirflag, &memo, &onwalk);
+      paths.reserve(std::min(cnt, kMaxAllelePaths));
+    }
     std::vector<int> seq;
     dfs_paths(b, b.sink, dirflag, &seq, &paths);
     return paths;

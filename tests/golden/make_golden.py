@@ -148,6 +148,30 @@ def multi():
     return gfa, "\n".join(lines) + "\n"
 
 
+def sbub():
+    """A chain simple bubble - SUPERBUBBLE - simple bubble.  The superbubble 4 -> 12 has seven
+    inner nodes (5..11, two stacked levels of branching) and six source-sink paths: the
+    reference lists them depth-first from the sink in link order (findPathsComplex,
+    src/chainstoreadset.cpp:84-116, quirk Q7); the L lines are written in an order that makes
+    the listing differ from the sorted one."""
+    S = [f"S\t{utg(i)}\tA" for i in range(1, 16)]
+    L = []
+    E = [(1, 2), (1, 3), (2, 4), (3, 4),
+         (4, 6), (4, 5), (5, 8), (5, 7), (6, 8), (6, 9), (7, 10), (8, 11), (8, 10), (9, 11), (10, 12), (11, 12),
+         (12, 13), (12, 14), (13, 15), (14, 15)]
+    for a, b in E:
+        L += link(a, "+", b, "+")
+    gfa = "\n".join(S + L) + "\n"
+    reads = [("s1", [1, 2, 4, 5, 7, 10, 12, 13, 15], "0.97"), ("s2", [1, 3, 4, 6, 9, 11, 12, 14, 15], "0.96"),
+             ("s3", [2, 4, 5, 8, 11, 12, 13], "0.95"), ("s4", [3, 4, 6, 8, 10, 12, 14, 15], "0.98"),
+             ("s5", [1, 2, 4, 5, 7, 10, 12], "0.99"), ("s6", [4, 6, 9, 11, 12, 14, 15], "0.94")]
+    lines = []
+    for name, nodes, ident in reads:
+        path = "".join(">" + utg(n) for n in nodes)
+        lines.append(f"{name}\t1000\t0\t1000\t+\t{path}\t1000\t0\t1000\t1000\t1000\t60\tNM:i:0\tAS:f:0\tdv:f:0\tid:f:{ident}")
+    return gfa, "\n".join(lines) + "\n"
+
+
 S1_SIZES = list(range(2, 31)) + [47, 59, 60, 97, 127, 128, 199, 257, 500, 541, 1000]
 
 
@@ -166,7 +190,11 @@ def main():
     gfa, gaf = multi()
     open(os.path.join(HERE, "multi.gfa"), "w").write(gfa)
     open(os.path.join(HERE, "multi.gaf"), "w").write(gaf)
-    for stem in ("c1", "toy", "multi"):
+    # fixture 2d: a seven-inner-node superbubble (allele-path listing order of findPathsComplex)
+    gfa, gaf = sbub()
+    open(os.path.join(HERE, "sbub.gfa"), "w").write(gfa)
+    open(os.path.join(HERE, "sbub.gaf"), "w").write(gaf)
+    for stem in ("c1", "toy", "multi", "sbub"):
         out = subprocess.run([REF_DUMP, os.path.join(HERE, stem + ".gfa"), os.path.join(HERE, stem + ".gaf")],
                              capture_output=True, text=True, check=True).stdout
         open(os.path.join(HERE, stem + ".ref.txt"), "w").write(out)

@@ -15,7 +15,7 @@ from ahsoka_amd import capi
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("stem", ["c1", "toy", "multi"])
+@pytest.mark.parametrize("stem", ["c1", "toy", "multi", "sbub"])
 def test_dump_equals_reference(stem, tmp_path):
     out = str(tmp_path / "dump.txt")
     capi.ingest_dump(os.path.join(GOLD, stem + ".gfa"), os.path.join(GOLD, stem + ".gaf"), out)
@@ -41,7 +41,7 @@ def _parse(path):
     return chains, alleles, alns, order, s1
 
 
-@pytest.mark.parametrize("stem", ["c1", "toy", "multi"])
+@pytest.mark.parametrize("stem", ["c1", "toy", "multi", "sbub"])
 def test_batch_equals_reference(stem):
     chains, alleles, alns, order, s1 = _parse(os.path.join(GOLD, stem + ".ref.txt"))
     b = capi.ingest(os.path.join(GOLD, stem + ".gfa"), os.path.join(GOLD, stem + ".gaf"))
@@ -114,6 +114,62 @@ def test_dump_live_against_reference_build(tmp_path):
     out = str(tmp_path / "dump.txt")
     capi.ingest_dump(g, a, out)
     assert open(out).read() == exp
+
+
+def test_superbubble_path_listing():
+    """seven inner nodes, six paths, listed sink -> source depth-first in link order (quirk Q7);
+    a ladder of 12 stacked sub-bubbles (4096 paths) stops at the 1024-path bound instead of
+    walking all of it -- such a chain is beyond the device's 16 alleles anyway"""
+    ref = [ln.split() for ln in open(os.path.join(GOLD, "sbub.ref.txt")) if ln.startswith("ALLELE 0 1 ")]
+    assert len(ref) == 6 and all(t[4] == "5" for t in ref)
+    listed = [tuple(int(x) for x in t[5:10]) for t in ref]
+    # the reference sees this bubble as source 12, sink 4 (BUBBLE line): paths run sink -> source, in link order
+    assert listed != sorted(listed) and all(p[0] == 4 and p[-1] == 12 for p in listed)
+    b = capi.ingest(os.path.join(GOLD, "sbub.gfa"), os.path.join(GOLD, "sbub.gaf"))
+    a = b.arrays()
+    assert np.diff(a["allele_off"]).tolist() == [2, 6, 2]
+
+
+def test_allele_path_bound(tmp_path):
+    import time
+    S, L = [], []
+
+    def utg(i):
+        return f"utg{i:06d}l"
+
+    def link(x, y):
+        return [f"L\t{utg(x)}\t+\t{utg(y)}\t+\t0M", f"L\t{utg(y)}\t-\t{utg(x)}\t-\t0M"]
+    # simple bubble, then ONE superbubble made of 22 stacked diamonds closed by a long bypass
+    # node (so that no inner junction is itself a bubble end), then a simple bubble
+    K = 22
+    nid = 1
+    edges = [(1, 2), (1, 3), (2, 4), (3, 4)]
+    junction = 4
+    first = junction
+    nid = 5
+    for _ in range(K):
+        a, bq, j = nid, nid + 1, nid + 2
+        edges += [(junction, a), (junction, bq), (a, j), (bq, j)]
+        junction = j
+        nid += 3
+    bypass = nid
+    edges += [(first, bypass), (bypass, junction)]
+    nid += 1
+    edges += [(junction, nid), (junction, nid + 1), (nid, nid + 2), (nid + 1, nid + 2)]
+    for i in range(1, nid + 3):
+        S.append(f"S\t{utg(i)}\tA")
+    for x, y in edges:
+        L += link(x, y)
+    gfa = tmp_path / "ladder.gfa"
+    gfa.write_text("\n".join(S + L) + "\n")
+    gaf = tmp_path / "ladder.gaf"
+    gaf.write_text("")
+    t0 = time.time()
+    b = capi.ingest(str(gfa), str(gaf))
+    dt = time.time() - t0
+    na = np.diff(b.arrays()["allele_off"])
+    assert dt < 5.0                       # 2^22 paths are not walked
+    assert na.max() == 1024               # the bound; > 16 alleles => the device reports the chain UNSUPPORTED
 
 
 def test_identity_truncation():
