@@ -151,6 +151,16 @@ def test_reads_with_foreign_nodes_and_empty_middle():
     _compare(b, capi.default_params(want_stages=1))
 
 
+def test_superbubble_fixture():
+    """a seven-inner-node superbubble with six allele paths listed sink -> source (quirk Q7),
+    between two simple bubbles: complex allele paths through the match kernel"""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    b = capi.ingest(os.path.join(gold, "sbub.gfa"), os.path.join(gold, "sbub.gaf"))
+    g, _ = _compare(b, capi.default_params(want_stages=1))
+    assert g.status[0] == capi.ST_PHASED and g.stages["vfull"].max() >= 3
+
+
 def test_c1_text_roundtrip_through_ingest():
     import os
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
