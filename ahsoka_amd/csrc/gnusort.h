@@ -10,8 +10,16 @@
 // std::sort is not stable, so read indices and cluster order depend on the
 // exact sequence of comparisons and moves.  This is an
 // independent implementation of the published algorithm, iterative (explicit
-// stack) so it runs on one GPU lane; tests/test_gnusort.py pins it against
-// the real std::sort of this toolchain on tie-heavy and adversarial inputs.
+// stack); tests/test_gnusort.py pins it against the real std::sort of this
+// toolchain on tie-heavy and adversarial inputs.
+//
+// The algorithm is written against an ARRAY ACCESSOR (get(i) / set(i, v)), so the
+// same code sorts a plain array (host test hook, small device arrays) or an array
+// held in the vector registers of one wavefront (WaveRegArray, k_readset.hip:
+// element i in lane i & 63 of register i >> 6, reached with v_readlane /
+// v_writelane).  The sort is inherently sequential -- the tie order IS the
+// sequence of comparisons -- so what can be made fast is the access: ~10 cycles
+// per element in registers against ~100 for a dependent LDS read.
 #pragma once
 #include <stdint.h>
 
@@ -23,63 +31,70 @@
 
 namespace ahk {
 
-template <class T, class Less>
-AHK_HDN inline void gs_unguarded_linear_insert(T* a, int last, Less less) {
-  T val = a[last];
+template <class T>
+struct PtrArray {
+  T* p;
+  AHK_HDN T get(int i) const { return p[i]; }
+  AHK_HDN void set(int i, T v) { p[i] = v; }
+};
+
+template <class A, class Less>
+AHK_HDN inline void gs_unguarded_linear_insert(A& a, int last, Less less) {
+  const auto val = a.get(last);
   int next = last - 1;
-  while (less(val, a[next])) {
-    a[last] = a[next];
+  while (less(val, a.get(next))) {
+    a.set(last, a.get(next));
     last = next;
     --next;
   }
-  a[last] = val;
+  a.set(last, val);
 }
 
-template <class T, class Less>
-AHK_HDN inline void gs_insertion_sort(T* a, int first, int last, Less less) {
+template <class A, class Less>
+AHK_HDN inline void gs_insertion_sort(A& a, int first, int last, Less less) {
   if (first == last) return;
   for (int i = first + 1; i != last; ++i) {
-    if (less(a[i], a[first])) {
-      T val = a[i];
-      for (int k = i; k > first; --k) a[k] = a[k - 1];
-      a[first] = val;
+    if (less(a.get(i), a.get(first))) {
+      const auto val = a.get(i);
+      for (int k = i; k > first; --k) a.set(k, a.get(k - 1));
+      a.set(first, val);
     } else {
       gs_unguarded_linear_insert(a, i, less);
     }
   }
 }
 
-template <class T, class Less>
-AHK_HDN inline void gs_adjust_heap(T* a, int first, int hole, int len, T value, Less less) {
+template <class A, class T, class Less>
+AHK_HDN inline void gs_adjust_heap(A& a, int first, int hole, int len, T value, Less less) {
   const int top = hole;
   int child = hole;
   while (child < (len - 1) / 2) {
     child = 2 * (child + 1);
-    if (less(a[first + child], a[first + child - 1])) child--;
-    a[first + hole] = a[first + child];
+    if (less(a.get(first + child), a.get(first + child - 1))) child--;
+    a.set(first + hole, a.get(first + child));
     hole = child;
   }
   if ((len & 1) == 0 && child == (len - 2) / 2) {
     child = 2 * (child + 1);
-    a[first + hole] = a[first + child - 1];
+    a.set(first + hole, a.get(first + child - 1));
     hole = child - 1;
   }
   int parent = (hole - 1) / 2;
-  while (hole > top && less(a[first + parent], value)) {
-    a[first + hole] = a[first + parent];
+  while (hole > top && less(a.get(first + parent), value)) {
+    a.set(first + hole, a.get(first + parent));
     hole = parent;
     parent = (hole - 1) / 2;
   }
-  a[first + hole] = value;
+  a.set(first + hole, value);
 }
 
-template <class T, class Less>
-AHK_HDN inline void gs_heapsort(T* a, int first, int last, Less less) {
+template <class A, class Less>
+AHK_HDN inline void gs_heapsort(A& a, int first, int last, Less less) {
   const int len = last - first;
   if (len >= 2) {
     int parent = (len - 2) / 2;
     for (;;) {
-      T v = a[first + parent];
+      const auto v = a.get(first + parent);
       gs_adjust_heap(a, first, parent, len, v, less);
       if (parent == 0) break;
       parent--;
@@ -88,45 +103,49 @@ AHK_HDN inline void gs_heapsort(T* a, int first, int last, Less less) {
   int l = last;
   while (l - first > 1) {
     --l;
-    T v = a[l];
-    a[l] = a[first];
+    const auto v = a.get(l);
+    a.set(l, a.get(first));
     gs_adjust_heap(a, first, 0, l - first, v, less);
   }
 }
 
-template <class T>
-AHK_HDN inline void gs_swap(T& x, T& y) {
-  T t = x;
-  x = y;
-  y = t;
+template <class A>
+AHK_HDN inline void gs_swap(A& a, int i, int j) {
+  const auto t = a.get(i);
+  a.set(i, a.get(j));
+  a.set(j, t);
 }
 
-template <class T, class Less>
-AHK_HDN inline int gs_partition_pivot(T* a, int first, int last, Less less) {
-  int mid = first + (last - first) / 2;
+template <class A, class Less>
+AHK_HDN inline int gs_partition_pivot(A& a, int first, int last, Less less) {
+  const int mid = first + (last - first) / 2;
   // move median of a[first+1], a[mid], a[last-1] to a[first]
-  int ia = first + 1, ib = mid, ic = last - 1;
-  if (less(a[ia], a[ib])) {
-    if (less(a[ib], a[ic])) gs_swap(a[first], a[ib]);
-    else if (less(a[ia], a[ic])) gs_swap(a[first], a[ic]);
-    else gs_swap(a[first], a[ia]);
-  } else if (less(a[ia], a[ic])) gs_swap(a[first], a[ia]);
-  else if (less(a[ib], a[ic])) gs_swap(a[first], a[ic]);
-  else gs_swap(a[first], a[ib]);
+  const int ia = first + 1, ib = mid, ic = last - 1;
+  {
+    const auto va = a.get(ia), vb = a.get(ib), vc = a.get(ic);
+    if (less(va, vb)) {
+      if (less(vb, vc)) gs_swap(a, first, ib);
+      else if (less(va, vc)) gs_swap(a, first, ic);
+      else gs_swap(a, first, ia);
+    } else if (less(va, vc)) gs_swap(a, first, ia);
+    else if (less(vb, vc)) gs_swap(a, first, ic);
+    else gs_swap(a, first, ib);
+  }
+  const auto pivot = a.get(first);  // (a[first] is not touched by the partition loop)
   int lo = first + 1, hi = last;
   for (;;) {
-    while (less(a[lo], a[first])) ++lo;
+    while (less(a.get(lo), pivot)) ++lo;
     --hi;
-    while (less(a[first], a[hi])) --hi;
+    while (less(pivot, a.get(hi))) --hi;
     if (!(lo < hi)) return lo;
-    gs_swap(a[lo], a[hi]);
+    gs_swap(a, lo, hi);
     ++lo;
   }
 }
 
-// sorts a[0..n)
-template <class T, class Less>
-AHK_HDN inline void gnu_sort(T* a, int n, Less less) {
+// sorts a[0..n); st0/st1/st2: three scratch arrays of 64 ints (the stack of pending ranges)
+template <class A, class S, class Less>
+AHK_HDN inline void gnu_sort_acc(A& a, int n, Less less, S& st_first, S& st_last, S& st_depth) {
   if (n <= 0) return;
   int depth = 0;
   for (int t = n; t > 1; t >>= 1) depth++;
@@ -135,21 +154,24 @@ AHK_HDN inline void gnu_sort(T* a, int n, Less less) {
   // recursive call is on the RIGHT part, the loop continues on the left, so
   // right parts are stacked and processed after the left spine -- the order
   // does not matter for the result (the ranges are disjoint).
-  int stk_first[64], stk_last[64], stk_depth[64];
   int sp = 0;
-  stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = depth;
+  st_first.set(0, 0);
+  st_last.set(0, n);
+  st_depth.set(0, depth);
   sp = 1;
   while (sp > 0) {
     --sp;
-    int first = stk_first[sp], last = stk_last[sp], d = stk_depth[sp];
+    int first = st_first.get(sp), last = st_last.get(sp), d = st_depth.get(sp);
     while (last - first > 16) {
       if (d == 0) {
         gs_heapsort(a, first, last, less);
         break;
       }
       --d;
-      int cut = gs_partition_pivot(a, first, last, less);
-      stk_first[sp] = cut; stk_last[sp] = last; stk_depth[sp] = d;
+      const int cut = gs_partition_pivot(a, first, last, less);
+      st_first.set(sp, cut);
+      st_last.set(sp, last);
+      st_depth.set(sp, d);
       ++sp;
       last = cut;
     }
@@ -160,6 +182,15 @@ AHK_HDN inline void gnu_sort(T* a, int n, Less less) {
   } else {
     gs_insertion_sort(a, 0, n, less);
   }
+}
+
+// plain array form
+template <class T, class Less>
+AHK_HDN inline void gnu_sort(T* a, int n, Less less) {
+  int stk[3][64];
+  PtrArray<T> arr{a};
+  PtrArray<int> s0{stk[0]}, s1{stk[1]}, s2{stk[2]};
+  gnu_sort_acc(arr, n, less, s0, s1, s2);
 }
 
 struct LessHi16 {

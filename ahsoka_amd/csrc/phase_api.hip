@@ -68,6 +68,9 @@ struct ahsoka_device_batch {
   std::vector<void*> ws_allocs;  // slot workspaces (released as a whole if their allocation fails)
   DeviceBatch db;
   ReadsetLds rl;
+  ReadsetLds2 rl2;
+  int* rs_list = nullptr;  // device: chains of k_readset_lds first, then those of k_readset
+  int n_fit = 0, n_big = 0, n_fit_real = 0;
   std::vector<PhaseClass> classes;
   int* qheads = nullptr;
   int maxG = 1, maxB = 1, n_cu = 1;
@@ -218,6 +221,9 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   std::vector<unsigned char> apath_dup((size_t)in->allele_off[in->bubble_off[C]] + 1, 0);
   int maxA = 2, maxG = 1, maxB = 1, maxN = 1;
   long long vm = 0, fr = 0, cov = 0, dump = 0;
+  std::vector<int> fit_list, big_list;
+  h->rl2 = ReadsetLds2{1, 1, 1, 1, 1, 1};
+  h->maxB = 1;
   for (int c = 0; c < C; c++) {
     ChainMeta& m = h->meta[c];
     std::memset(&m, 0, sizeof(m));
@@ -259,13 +265,35 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
             if (in->apath_node[e] == in->apath_node[e2]) { apath_dup[(size_t)a] = 1; break; }
       }
     }
-    m.flags = unsupported ? 1 : 0;
-    m.vmat0 = vm;
+    // chains whose alignment bitsets fit the LDS as a whole take k_readset_lds: no R x B match
+    // matrices in HBM unless the stage dumps are wanted
+    const long long SAc = in->allele_off[m.b0 + m.B] - in->allele_off[m.b0];
+    const ReadsetLds2 need2{(int)std::min<long long>((long long)((m.N + 63) / 64) * m.R, 1 << 28),
+                            (int)std::min<long long>((long long)((m.N + 63) / 64) * SAc, 1 << 28),
+                            m.R, std::max(G, 1), std::max(m.B, 1), (int)std::min<long long>(SAc, 65535)};
+    const bool fit = unsupported || m.B <= 1 ||
+                     (SAc < 65535 && readset_lds2_bytes(need2) <= std::min<size_t>(h->lds_per_block, kReadsetFitBytes));
+    m.flags = (unsupported ? 1 : 0) | (fit ? 2 : 0);
+    m.vmat0 = (fit && !prm->want_stages) ? -1 : vm;
     m.fr0 = fr;
     m.cov0 = cov;
     m.pos0 = m.b0;
     m.dump0 = -1;
-    vm += (long long)m.R * m.B;
+    if (m.vmat0 >= 0) vm += (long long)m.R * m.B;
+    if (fit) {
+      fit_list.push_back(c);
+      if (!unsupported && m.B > 1) {
+        h->n_fit_real++;
+        h->rl2.maxBitWords = std::max(h->rl2.maxBitWords, need2.maxBitWords);
+        h->rl2.maxMaskWords = std::max(h->rl2.maxMaskWords, need2.maxMaskWords);
+        h->rl2.maxSA = std::max(h->rl2.maxSA, need2.maxSA);
+        h->rl2.maxR = std::max(h->rl2.maxR, m.R);
+        h->rl2.maxG = std::max(h->rl2.maxG, std::max(G, 1));
+        h->rl2.maxB = std::max(h->rl2.maxB, std::max(m.B, 1));
+      }
+    } else {
+      big_list.push_back(c);
+    }
     fr += G;
     cov += (long long)G * m.Wb;
     if (prm->want_stages) {
@@ -273,9 +301,12 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
       dump += (long long)std::min(G, kMaxReads) * std::min(G, kMaxReads);
     }
     if (!unsupported && m.B > 1) {
-      maxG = std::max(maxG, G);
-      maxB = std::max(maxB, m.B);
-      maxN = std::max(maxN, m.N);
+      h->maxB = std::max(h->maxB, m.B);
+      if (!fit) {
+        maxG = std::max(maxG, G);
+        maxB = std::max(maxB, m.B);
+        maxN = std::max(maxN, m.N);
+      }
     }
   }
   h->sumB = in->bubble_off[C];
@@ -339,6 +370,12 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   if ((rc = h->dalloc(&db.fr_cluster, (size_t)fr))) return fail(rc);
   if ((rc = h->dalloc(&db.cover, (size_t)cov))) return fail(rc);
   if ((rc = h->dalloc(&db.alle, (size_t)cov * planes))) return fail(rc);
+  if (h->n_fit_real > 0) {  // creation-ordered staging of k_readset_lds (k_sortperm writes the final arrays)
+    if ((rc = h->dalloc(&db.cover_tmp, (size_t)cov))) return fail(rc);
+    if ((rc = h->dalloc(&db.alle_tmp, (size_t)cov * planes))) return fail(rc);
+    if ((rc = h->dalloc(&db.sortkey, (size_t)fr))) return fail(rc);
+    if ((rc = h->dalloc(&db.name_tmp, (size_t)fr))) return fail(rc);
+  }
   db.alle_plane_stride = cov;
   db.planes = planes;
   if ((rc = h->dalloc(&db.hap_allele, (size_t)SB * prm->ploidy))) return fail(rc);
@@ -363,7 +400,15 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   h->rl.maxG = maxG;
   h->rl.maxB = maxB;
   h->maxG = maxG;
-  h->maxB = maxB;
+  h->n_fit = (int)fit_list.size();
+  h->n_big = (int)big_list.size();
+  {
+    std::vector<int> both(fit_list);
+    both.insert(both.end(), big_list.begin(), big_list.end());
+    const int* q = nullptr;
+    if ((rc = h->dupload(&q, both.data(), both.size()))) return fail(rc);
+    h->rs_list = const_cast<int*>(q);
+  }
   // (the k_phase queues and slot workspaces are built after the first k_readset, when
   // the sizes of the final readsets are known: see build_classes)
 #ifdef AHK_DIAG
@@ -540,7 +585,8 @@ extern "C" int ahsoka_phase_device(ahsoka_device_batch* h) {
   if (h->C == 0) return AHSOKA_OK;
   auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-  launch_readset(h->db, h->C, h->rl, h->stream);
+  launch_readset_lds(h->db, h->rs_list, h->n_fit, h->rl2, h->stream);
+  launch_readset(h->db, h->rs_list + h->n_fit, h->n_big, h->rl, h->stream);
   HIP_TRY(hipGetLastError());
   if (!h->ws_ready) {  // first call only: size classes and slot pools from the real readsets
     HIP_TRY(hipStreamSynchronize(h->stream));

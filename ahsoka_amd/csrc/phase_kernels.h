@@ -13,6 +13,7 @@ constexpr int kMaxReads = 2048;     // reads in the final readset (k_phase LDS)
 constexpr int kMaxAlleles = 16;     // alleles per bubble (4 bit planes)
 constexpr int kMaxPloidy = 4;       // tuples = (2p)^p <= 4096
 constexpr int kBlock = 256;         // threads per workgroup (4 wavefronts)
+constexpr size_t kReadsetFitBytes = 64 * 1024;  // LDS budget of k_readset_lds per chain (two or more workgroups per CU)
 
 constexpr int32_t W_PERM = 0x7fffffff;
 constexpr int32_t W_FORB = -0x7fffffff;  // -INT_MAX: its negation is W_PERM
@@ -27,14 +28,14 @@ struct ChainMeta {
   long long r0;        // first alignment
   long long n0;        // first node
   long long name0;     // first entry of name_off (per-chain CSR name -> alignments)
-  long long vmat0;     // offset of this chain's R*B match matrices
+  long long vmat0;     // offset of this chain's R*B match matrices, -1: none (k_readset_lds without stage dumps)
   long long fr0;       // offset of per-final-read arrays (capacity = G)
   long long cov0;      // offset of cover words (capacity G * Wb)
   long long pos0;      // offset of pos[] output (capacity B)
   long long dump0;     // offset into score dump (n*n) or -1
   int B, R, N, G;      // bubbles, alignments, nodes, distinct names
   int Wb;              // ceil(B/64): words of a position bit mask
-  int flags;           // bit0: chain exceeds a device limit
+  int flags;           // bit0: chain exceeds a device limit; bit1: alignment bitsets fit the LDS (k_readset_lds)
   int pad0, pad1;
 };
 
@@ -64,6 +65,11 @@ struct DeviceBatch {
   int* fr_name;        // [sum G]
   unsigned long long* cover;  // [sum G*Wb] word-major: cover[w*G + i]
   unsigned long long* alle;   // [planes][sum G*Wb]
+  // k_readset_lds -> k_sortperm: the same in creation order, the sort keys, the names
+  unsigned long long* cover_tmp;
+  unsigned long long* alle_tmp;
+  unsigned int* sortkey;      // [sum G]
+  int* name_tmp;              // [sum G]
   long long alle_plane_stride;
   int planes;
   // k_phase outputs
@@ -114,8 +120,15 @@ struct PhaseLds {
   int nmax;        // capacity of the per-read LDS arrays
   int stop_after;  // diagnostic builds (-DAHK_DIAG) only: 1/2/3 = stop after S4 / S5 init / S5 loop
 };
+struct ReadsetLds2 {  // k_readset_lds
+  int maxBitWords;   // max over its chains of ceil(N/64) * R: u64 words of all alignment bitsets
+  int maxMaskWords;  // max of ceil(N/64) * alleles: u64 words of one set of allele-path masks
+  int maxR, maxG, maxB, maxSA;
+};
 size_t readset_lds_bytes(const ReadsetLds& l);
-void launch_readset(const DeviceBatch& db, int C, const ReadsetLds& l, hipStream_t stream);
+size_t readset_lds2_bytes(const ReadsetLds2& l);
+void launch_readset(const DeviceBatch& db, const int* list, int count, const ReadsetLds& l, hipStream_t stream);
+void launch_readset_lds(const DeviceBatch& db, const int* list, int count, const ReadsetLds2& l, hipStream_t stream);
 size_t phase_lds_bytes(const PhaseLds& l);
 void launch_phase(const DeviceBatch& db, const SlotWorkspace& ws, const PhaseLds& l, const int* queue, int C, int* qhead,
                   int slots, hipStream_t stream);

@@ -10,7 +10,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
-    if 'k_phase' in r['Kernel_Name'] or 'k_readset' in r['Kernel_Name']:
+    if any(k in r['Kernel_Name'] for k in ('k_phase', 'k_readset', 'k_sortperm')):
         print(sys.argv[2], r['Kernel_Name'][:20], r['Counter_Name'], r['Counter_Value'])
 PY
 done
