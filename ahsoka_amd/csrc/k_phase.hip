@@ -1603,8 +1603,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     // all of them when none conforms.
     {
       const long long Tmax = ws.Tmax;
-      if (wv == 0) {
-        for (int j = 0; j < P; j++) {
+      {
+        for (int j = wv; j < P; j += 4) {  // one wave per position
           const int k = tp_k[j];
           int T = 1;
           for (int i = 0; i < ploidy; i++) T *= k;
@@ -1689,11 +1689,27 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         __syncthreads();
       }
       // ---- backtrace + S8 -------------------------------------------------
-      if (tid == 0) {
-        int cur = 0;
+      // final state: the FIRST minimum of the last column.  Scores are non-negative doubles
+      // (their bit patterns order like the values), so lane-strided running minima of
+      // (score bits, index) pairs and one 64-bit DPP min-reduce of the bits, then of the
+      // indices among the lanes that hold the minimum, pick exactly the tuple a sequential
+      // scan with strict '<' picks.
+      if (wv == 0) {
         const int ntl = tp_ntup[P - 1];
-        for (int r = 1; r < ntl; r++)
-          if (tp_score[(size_t)(P - 1) * Tmax + r] < tp_score[(size_t)(P - 1) * Tmax + cur]) cur = r;
+        unsigned long long bs = ~0ull;
+        int br = 0x7fffffff;
+        for (int r = lane; r < ntl; r += 64) {
+          const unsigned long long v = (unsigned long long)__double_as_longlong(tp_score[(size_t)(P - 1) * Tmax + r]);
+          if (v < bs) { bs = v; br = r; }  // (ascending r per lane: ties keep the lower index)
+        }
+        const unsigned long long gmin = ~wave_max_u64(~bs);
+        const unsigned long long idxkey = bs == gmin ? (unsigned long long)(0x7fffffff - br) : 0ull;
+        const int cur0 = 0x7fffffff - (int)wave_max_u64(idxkey);
+        if (lane == 0) s_back = cur0;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int cur = s_back;
         int* ha = db.hap_allele + (long long)ploidy * m.pos0;
         int* hc = db.hap_cluster + (long long)ploidy * m.pos0;
         for (int j = P - 1; j >= 0; j--) {

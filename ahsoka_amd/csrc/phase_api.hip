@@ -192,6 +192,8 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
                                    ahsoka_device_batch** handle) {
   if (!in || !prm || !handle) return AHSOKA_E_ARG;
   if (prm->ploidy < 2 || prm->ploidy > kMaxPloidy || prm->min_overlap < 0 || prm->max_slots < 0) return AHSOKA_E_ARG;
+  // (threading scores must be non-negative: the device argmin orders them by their bit patterns)
+  if (!(prm->switch_cost >= 0.0) || !(prm->affine_switch_cost >= 0.0)) return AHSOKA_E_ARG;
   if (int e = ahk::validate_batch(in)) return e;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return AHSOKA_E_NODEVICE;
