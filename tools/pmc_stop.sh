@@ -1,5 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+make -s -C ahsoka_amd/csrc clean >/dev/null; make -s -C ahsoka_amd/csrc ../libahsoka_phase.so EXTRA="-DAHK_DIAG" 2>&1 | grep -E "error"
 for sa in 2 0; do
   AHSOKA_STOP_AFTER=$sa rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_stop$sa -- python3 bench.py --chains 1280 --steps 1 --warmup 0 --cpu-sample 0 > gpurun_out/pmc_stop$sa.log 2>&1
   f=$(ls -t gpurun_out/pmc_stop$sa/*/*counter_collection.csv | head -1)
