@@ -338,6 +338,9 @@ constexpr int kFastBatch = AHK_FAST_BATCH;  // live words of a row a wave of the
 #define AHK_P3B_CH 4
 #endif
 constexpr int kP3bChunk = AHK_P3B_CH;  // triangles per load batch of an edge in P3b
+#ifndef AHK_S7_MARGINAL
+#define AHK_S7_MARGINAL 1  // threading DP: predecessor minimum by marginal minima, O(T 2^p), instead of the O(T^2) scan
+#endif
 #ifndef AHK_HEAVY
 #define AHK_HEAVY 1  // P3b, edges with long member lists: 1 = member lists in chunks over all lanes; 2 = one wave per edge, lanes = members; 0 = off
 #endif
@@ -476,6 +479,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
   int* tp_tuples = ws.tp_tuples + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
   double* tp_score = ws.tp_score + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
   unsigned short* tp_pred = ws.tp_pred + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
+  double* tp_best = ws.tp_best + (size_t)blockIdx.x * ws.Tmax;
 
   const int ploidy = db.ploidy;
 
@@ -1670,6 +1674,136 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             tp_pred[r] = 0xffff;
             continue;
           }
+#if AHK_S7_MARGINAL
+          // (the predecessor minimum is taken below, by marginal minima; here: the column cost)
+          tp_score[(size_t)j * Tmax + r] = cc;
+        }
+        __syncthreads();
+        if (j == 0) continue;  // (uniform)
+        // ---- predecessor minimum by MARGINAL MINIMA: O(T * 2^p) instead of O(T^2) ----------
+        // The transition cost depends only on how many slots change cluster: with A(q,r) the set
+        // of slots on which predecessor q and tuple r agree, cost = c(p - |A|), c(m) =
+        // switch*m + (m > 0 ? affine : 0), non-decreasing in m (both parameters >= 0).  Hence
+        //   min_q [score(q) + c(p - |A(q,r)|)] = min over subsets S of the slots of
+        //       c(p - |S|) + min { score(q) : q agrees with r on (at least) S }
+        // -- a predecessor that agrees on more than S is merely over-charged under S and
+        // appears with its true cost under its own set.  For every S one table over the
+        // clusters of the previous position holds the minimum score of the predecessors with
+        // given clusters on S (LDS, ds_min_u64 on the bit patterns of the non-negative doubles)
+        // and, among the predecessors that reach it, the lowest list index; S = all slots is a
+        // plain lookup of the tuple code.  Taking candidates in (value, index) order reproduces
+        // the first minimum of the sequential scan, strict '<' and all: a tie partner with a
+        // lower index wins its own class or loses it to an even lower index of equal value.
+        {
+          unsigned short* idxmap = (unsigned short*)smem;                          // [kp^p] tuple code -> list index
+          int pw[kMaxPloidy + 1];
+          pw[0] = 1;
+#pragma unroll
+          for (int i = 1; i <= kMaxPloidy; i++) pw[i] = pw[i - 1] * kp;
+          const int ncode = pw[ploidy];
+          unsigned long long* tabS = (unsigned long long*)(idxmap + ((ncode + 3) & ~3));  // [kp^(p-1)] min score bits
+          unsigned int* tabQ = (unsigned int*)(tabS + pw[ploidy - 1]);                      // [kp^(p-1)] lowest index reaching it
+          const int* tup_prev = tp_tuples + (size_t)(j - 1) * Tmax;
+          const double* sc_prev = tp_score + (size_t)(j - 1) * Tmax;
+          for (int cidx2 = tid; cidx2 < ncode; cidx2 += kBlock) idxmap[cidx2] = 0xffffu;
+          __syncthreads();
+          for (int q = tid; q < ntp; q += kBlock) idxmap[tup_prev[q]] = (unsigned short)q;
+          __syncthreads();
+          // slot i of tuple r lives in cluster gcid[j][t_i]: its index among the previous
+          // position's clusters (or -1) -- per thread, eight clusters at most
+          int locp[8];
+#pragma unroll
+          for (int t = 0; t < 8; t++) {
+            locp[t] = -1;
+            if (t < k) {
+              const int gid = tp_gcid[(size_t)j * 8 + t];
+              for (int l = 0; l < kp; l++)
+                if (tp_gcid[(size_t)(j - 1) * 8 + l] == gid) locp[t] = l;
+            }
+          }
+          auto loc_of = [&](int t) {  // (constant indices only: locp stays in registers)
+            int v = -1;
+#pragma unroll
+            for (int u = 0; u < 8; u++) v = (t == u) ? locp[u] : v;
+            return v;
+          };
+          // S = all slots: exact predecessor with the same clusters
+          for (int r = tid; r < nt; r += kBlock) {
+            int rem = tp_tuples[(size_t)j * Tmax + r];
+            int code = 0;
+            bool ok = true;
+            for (int i = ploidy - 1; i >= 0; i--) {
+              const int l = loc_of(rem % k);
+              rem /= k;
+              ok = ok && l >= 0;
+              code += (l < 0 ? 0 : l) * pw[ploidy - 1 - i];
+            }
+            double best = __builtin_inf();
+            int bq = 0;
+            if (ok) {
+              const unsigned int q0 = idxmap[code];
+              if (q0 != 0xffffu) {
+                best = sc_prev[q0] + (db.switch_cost * (double)0 + 0.0);
+                bq = (int)q0;
+              }
+            }
+            tp_best[r] = best;
+            tp_pred[(size_t)j * Tmax + r] = (unsigned short)bq;
+          }
+          const int nsub = (1 << ploidy) - 1;  // proper subsets
+          for (int S = 0; S < nsub; S++) {
+            const int nS = __popc((unsigned)S), sw = ploidy - nS;
+            const int nent = pw[nS];
+            for (int e = tid; e < nent; e += kBlock) { tabS[e] = ~0ull; tabQ[e] = 0xffffffffu; }
+            __syncthreads();
+            for (int pass = 0; pass < 2; pass++) {
+              for (int q = tid; q < ntp; q += kBlock) {
+                int rem = tup_prev[q];
+                int idx = 0, mul = 1;
+                for (int i = ploidy - 1; i >= 0; i--) {
+                  const int tq = rem % kp;
+                  rem /= kp;
+                  if ((S >> i) & 1) { idx += tq * mul; mul *= kp; }
+                }
+                const unsigned long long sb = (unsigned long long)__double_as_longlong(sc_prev[q]);
+                if (pass == 0) atomicMin(&tabS[idx], sb);
+                else if (sb == tabS[idx]) atomicMin(&tabQ[idx], (unsigned int)q);
+              }
+              __syncthreads();
+            }
+            const double add = db.switch_cost * (double)sw + (sw > 0 ? db.affine_cost : 0.0);
+            for (int r = tid; r < nt; r += kBlock) {
+              int rem = tp_tuples[(size_t)j * Tmax + r];
+              int idx = 0, mul = 1;
+              bool ok = true;
+              for (int i = ploidy - 1; i >= 0; i--) {
+                const int l = loc_of(rem % k);
+                rem /= k;
+                if ((S >> i) & 1) {
+                  ok = ok && l >= 0;
+                  idx += (l < 0 ? 0 : l) * mul;
+                  mul *= kp;
+                }
+              }
+              if (!ok) continue;
+              const unsigned long long sb = tabS[idx];
+              if (sb == ~0ull) continue;
+              const double v = __longlong_as_double((long long)sb) + add;
+              const int qq = (int)tabQ[idx];
+              const double best = tp_best[r];
+              const int bq = tp_pred[(size_t)j * Tmax + r];
+              if (v < best || (v == best && qq < bq)) {
+                tp_best[r] = v;
+                tp_pred[(size_t)j * Tmax + r] = (unsigned short)qq;
+              }
+            }
+            __syncthreads();
+          }
+          for (int r = tid; r < nt; r += kBlock) tp_score[(size_t)j * Tmax + r] = tp_score[(size_t)j * Tmax + r] + tp_best[r];
+        }
+        __syncthreads();
+      }
+#else
           double best = __builtin_inf();
           int bq = 0;
           for (int q = 0; q < ntp; q++) {
@@ -1688,6 +1822,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         }
         __syncthreads();
       }
+#endif
       // ---- backtrace + S8 -------------------------------------------------
       // final state: the FIRST minimum of the last column.  Scores are non-negative doubles
       // (their bit patterns order like the values), so lane-strided running minima of
@@ -1735,6 +1870,12 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4;  // multiw (padded to 8 bytes)
   b += 2 * 4 * 32 * 8;                                   // rmask, rolenz
   b += (size_t)l.nmax;                     // role
+  {  // the threading DP re-uses the region: tuple-code map (u16) + one marginal table (u64 + u32)
+    size_t codes = 1, marg = 1;
+    for (int i = 0; i < l.ploidy; i++) { marg = codes; codes *= (size_t)(2 * l.ploidy); }
+    const size_t s7 = ((codes + 3) & ~(size_t)3) * 2 + marg * 12 + 16;
+    if (s7 > b) b = s7;
+  }
   return (b + 15) & ~(size_t)15;
 }
 

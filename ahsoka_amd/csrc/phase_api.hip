@@ -460,7 +460,7 @@ static int build_classes(ahsoka_device_batch* h) {
   // largest readset whose per-read LDS arrays fit a workgroup of this device
   int ncap = 64;
   for (int v = 64; v <= ((kMaxReads + 63) & ~63); v += 64) {
-    PhaseLds t{v, 0};
+    PhaseLds t{v, 0, h->prm.ploidy};
     if (phase_lds_bytes(t) <= h->lds_per_block) ncap = v;
   }
   bool demoted = false;
@@ -506,6 +506,7 @@ static int build_classes(ahsoka_device_batch* h) {
     pc.count = (int)members[k].size();
     pc.pl.nmax = pc.nmax;
     pc.pl.stop_after = h->stop_after;
+    pc.pl.ploidy = h->prm.ploidy;
     for (int c : members[k]) pc.Pmax = std::max(pc.Pmax, h->meta[(size_t)c].B);
     const int per_cu = std::min(phase_max_blocks_per_cu(pc.pl), per_cu_cap);
     pc.slots = std::max(1, std::min(pc.count, h->n_cu * per_cu));
@@ -563,6 +564,7 @@ static int build_classes(ahsoka_device_batch* h) {
         (rc = wsalloc(&ws.tp_cons, S * ws.Pmax * 8)) || (rc = wsalloc(&ws.tp_consmap, S * ws.Pmax * 8)) ||
         (rc = wsalloc(&ws.tp_ntup, S * ws.Pmax)) || (rc = wsalloc(&ws.tp_tuples, S * ws.Pmax * ws.Tmax)) ||
         (rc = wsalloc(&ws.tp_score, S * ws.Pmax * ws.Tmax)) || (rc = wsalloc(&ws.tp_pred, S * ws.Pmax * ws.Tmax)) ||
+        (rc = wsalloc(&ws.tp_best, S * ws.Tmax)) ||
         (rc = wsalloc(&ws.sortbuf, S * 4 * ws.nmax))) {
       free_classes(h);
       return rc;

@@ -101,6 +101,7 @@ struct SlotWorkspace {
   int* tp_tuples;       // [slots][Pmax*Tmax]
   double* tp_score;     // [slots][Pmax*Tmax]
   unsigned short* tp_pred;  // [slots][Pmax*Tmax]
+  double* tp_best;          // [slots][Tmax] running predecessor minimum of the current position
   unsigned int* sortbuf;    // [slots][nmax] cluster sort scratch (per wave slices)
   long long nmax, Pmax, Tmax;
 };
@@ -119,6 +120,7 @@ struct ReadsetLds {
 struct PhaseLds {
   int nmax;        // capacity of the per-read LDS arrays
   int stop_after;  // diagnostic builds (-DAHK_DIAG) only: 1/2/3 = stop after S4 / S5 init / S5 loop
+  int ploidy;      // the threading DP's tables ((2p)^p tuple codes, (2p)^(p-1) marginal minima) share the LDS
 };
 struct ReadsetLds2 {  // k_readset_lds
   int maxBitWords;   // max over its chains of ceil(N/64) * R: u64 words of all alignment bitsets
