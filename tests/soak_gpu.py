@@ -25,9 +25,15 @@ def main():
     rng = np.random.default_rng(20261004)
     done = 0
     for k in range(n_random):
-        b = random_batch(50000 + k)
-        _compare(b, capi.default_params(want_stages=1, min_mapq=int(rng.choice([90, 93, 95])),
-                                        compaction_mode=int(k % 2)))
+        b = random_batch(50000 + k, dup_paths=(k % 5 == 0), n_chains=int(rng.choice([1, 4, 9])),
+                         max_bubbles=int(rng.choice([6, 14, 40])), max_reads=int(rng.choice([30, 120, 400])))
+        prm = capi.default_params(want_stages=1, min_mapq=int(rng.choice([90, 93, 95])), compaction_mode=int(k % 2),
+                                  max_slots=int(rng.choice([0, 0, 1, 3])))
+        g, _ = _compare(b, prm)
+        if k % 7 == 0:  # the device-list entry: shards on the same GPU, merged result identical
+            m = capi.phase_batch_multi(b, [0, 0, 0], prm)
+            np.testing.assert_array_equal(m.hap_allele, g.hap_allele)
+            np.testing.assert_array_equal(m.stages["score_q"], g.stages["score_q"])
         done += 1
         if done % 10 == 0:
             print(f"{done} cases ok", flush=True)
@@ -41,7 +47,8 @@ def main():
         nc = 3 if nr > 800 else 6
         b = capi.synth_batch(n_chains=nc, n_bubbles=nb, n_reads=nr, ploidy=ploidy, seed=7000 + k,
                              mean_span=float(rng.choice([3.0, 7.0, 15.0])), allele_err=float(rng.choice([0.0, 0.02, 0.15])))
-        _compare(b, capi.default_params(ploidy=ploidy, want_stages=1))
+        _compare(b, capi.default_params(ploidy=ploidy, want_stages=1, max_slots=int(rng.choice([0, 2])),
+                                        switch_cost=float(rng.choice([32.0, 5.0, 0.5])), affine_switch_cost=float(rng.choice([8.0, 0.0, 1.25]))))
         done += 1
         if done % 10 == 0:
             print(f"{done} cases ok (shape {nc}x{nb}x{nr} p{ploidy})", flush=True)
