@@ -341,6 +341,14 @@ constexpr int kP3bChunk = AHK_P3B_CH;  // triangles per load batch of an edge in
 #ifndef AHK_S7_MARGINAL
 #define AHK_S7_MARGINAL 1  // threading DP: predecessor minimum by marginal minima, O(T 2^p), instead of the O(T^2) scan
 #endif
+#ifndef AHK_HEAVY_WIDE
+#define AHK_HEAVY_WIDE 1
+#endif
+#if AHK_HEAVY_WIDE
+#define tri_seg_h tri_seg_wide
+#else
+#define tri_seg_h tri_seg
+#endif
 #ifndef AHK_HEAVY
 #define AHK_HEAVY 1  // P3b, edges with long member lists: 1 = member lists in chunks over all lanes; 2 = one wave per edge, lanes = members; 0 = off
 #endif
@@ -431,6 +439,33 @@ __device__ __forceinline__ void tri_seg(const int* __restrict__ Wm, int n, int x
       dp += icp_term(Nv, wbv[c]) - icp_term(ovv[c], wbv[c]);
     }
   }
+}
+
+
+// the same over a full chunk of the heavy-edge pass, EIGHT members per load batch: that pass is
+// a chain of dependent load batches per lane (its arithmetic hides behind other waves), so its
+// length is what counts; it has few live values, sixteen loads in flight fit the registers.
+template <int Nv>
+__device__ __forceinline__ void tri_seg_wide(const int* __restrict__ Wm, int n, int x, int b, const unsigned short* L, int cnt,
+                                             long long& df, long long& dp) {
+  int w0 = 0;
+  for (; w0 + 8 <= cnt; w0 += 8) {
+    const uint4 pk = *reinterpret_cast<const uint4*>(L + w0);
+    const int wq[8] = {(int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16),
+                       (int)(pk.z & 0xffffu), (int)(pk.z >> 16), (int)(pk.w & 0xffffu), (int)(pk.w >> 16)};
+    int ovv[8], wbv[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      ovv[c] = Wm[(unsigned)(x * n + wq[c])];
+      wbv[c] = Wm[(unsigned)(wq[c] * n + b)];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      df += icf_term(Nv, wbv[c]) - icf_term(ovv[c], wbv[c]);
+      dp += icp_term(Nv, wbv[c]) - icp_term(ovv[c], wbv[c]);
+    }
+  }
+  if (w0 < cnt) tri_seg<Nv>(Wm, n, x, b, L + w0, cnt - w0, df, dp);
 }
 
 #ifndef AHK_WAVES_PER_SIMD
@@ -1271,12 +1306,12 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
               if (c < ch1) {
                 const int o = c * kHeavyChunk;
                 const int cnt = n1 - o < kHeavyChunk ? n1 - o : kHeavyChunk;
-                if (merge && (rx == ROLE_A || rx == ROLE_B)) tri_seg<W_PERM>(Wm, n, x, b, L1 + o, cnt, df, dp);
-                else tri_seg<W_FORB>(Wm, n, x, b, L1 + o, cnt, df, dp);
+                if (merge && (rx == ROLE_A || rx == ROLE_B)) tri_seg_h<W_PERM>(Wm, n, x, b, L1 + o, cnt, df, dp);
+                else tri_seg_h<W_FORB>(Wm, n, x, b, L1 + o, cnt, df, dp);
               } else if (c < ch1 + ch2) {
                 const int o = (c - ch1) * kHeavyChunk;
                 const int cnt = n2 - o < kHeavyChunk ? n2 - o : kHeavyChunk;
-                tri_seg<W_FORB>(Wm, n, x, b, L2 + o, cnt, df, dp);
+                tri_seg_h<W_FORB>(Wm, n, x, b, L2 + o, cnt, df, dp);
               }
               if (df != 0) atomicAdd(&hacc[2 * hh], (unsigned long long)df);
               if (dp != 0) atomicAdd(&hacc[2 * hh + 1], (unsigned long long)dp);
