@@ -47,6 +47,24 @@ def test_argument_errors():
         capi.ingest("/nonexistent.gfa", "/nonexistent.gaf")
 
 
+def test_parameter_validation_precedes_the_device():
+    """bad parameters are argument errors whether or not a device exists"""
+    L = capi.lib()
+    b = capi.synth_batch(**capi.CONFIGS["c1"])
+    h = C.c_void_p()
+    for bad in (dict(ploidy=1), dict(ploidy=9), dict(min_overlap=-1), dict(max_slots=-1), dict(switch_cost=-1.0),
+                dict(affine_switch_cost=float("nan"))):
+        prm = capi.default_params(**bad)
+        assert L.ahsoka_batch_upload(b.ptr(), C.byref(prm), C.byref(h)) == capi.E_ARG, bad
+    # s1_order must be a permutation of the chain's bubble ids
+    a = b.arrays()
+    a["s1_order"] = a["s1_order"].copy()
+    a["s1_order"][1] = a["s1_order"][0]
+    bad_b = capi.ChainBatch(arrays={k: v for k, v in a.items() if v is not None})
+    prm = capi.default_params()
+    assert L.ahsoka_batch_upload(bad_b.ptr(), C.byref(prm), C.byref(h)) == capi.E_ARG
+
+
 def test_multi_device_entry_argument_errors():
     import numpy as np
 
