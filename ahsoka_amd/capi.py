@@ -111,7 +111,7 @@ ABI_SYMBOLS = [
     "ahsoka_result_free", "ahsoka_batch_upload", "ahsoka_phase_device", "ahsoka_batch_download",
     "ahsoka_batch_free", "ahsoka_batch_result_device", "ahsoka_batch_kernel_times", "ahsoka_batch_bytes", "ahsoka_render_chain",
     "ahsoka_ingest", "ahsoka_ingest_dump", "ahsoka_batch_host_free", "ahsoka_synth_batch", "ahsoka_synth_select", "ahsoka_synth_shapes", "ahsoka_synth_write_text", "ahsoka_synth_truth",
-    "ahsoka_test_introsort_u32", "ahsoka_test_detlog",
+    "ahsoka_test_introsort_u32", "ahsoka_test_introsort_par_u32", "ahsoka_test_detlog",
 ]
 
 _lib = None
@@ -158,6 +158,7 @@ def lib() -> C.CDLL:
     L.ahsoka_synth_truth.argtypes = [C.POINTER(CSynthSpec), u8p, C.c_int64]
     L.ahsoka_synth_truth.restype = C.c_int64
     L.ahsoka_test_introsort_u32.argtypes = [C.POINTER(C.c_uint32), C.c_int32]
+    L.ahsoka_test_introsort_par_u32.argtypes = [C.POINTER(C.c_uint32), C.c_int32]
     L.ahsoka_test_detlog.argtypes = [C.c_double]
     L.ahsoka_test_detlog.restype = C.c_double
     _lib = L

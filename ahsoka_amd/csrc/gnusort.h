@@ -193,6 +193,98 @@ AHK_HDN inline void gnu_sort(T* a, int n, Less less) {
   gnu_sort_acc(arr, n, less, s0, s1, s2);
 }
 
+// ---------------------------------------------------------------------------
+// The same permutation, computed in a form that parallelises (gnu_sort_par_ref is
+// its sequential statement, pinned against std::sort by tests/test_gnusort.py; the
+// wavefront version is in k_readset.hip).  Two facts about the algorithm above:
+//
+//  * The unguarded Hoare partition of [first+1,last) around the pivot a[first]
+//    only ever looks at ORIGINAL elements until its pointers cross: with
+//    l_1 < l_2 < ... the positions whose element is not less than the pivot and
+//    r_1 > r_2 > ... those whose element is not greater, it swaps (l_k, r_k) for
+//    k = 1..K, K = #{k : l_k < r_k} (a prefix, the sequences are monotone), and
+//    returns cut = min(l_{K+1}, r_K) (missing terms = +infinity).  Positions and K
+//    follow from prefix counts; the swaps touch disjoint positions.
+//  * After partitioning, every element left of a cut is <= every element right of
+//    it, and the final insertion sort moves an element left only past STRICTLY
+//    greater ones: no element ever crosses a cut.  The final pass is therefore an
+//    independent stable sort of every leaf range (<= 16 elements, or a range the
+//    depth limit handed to heapsort, which is sorted already): each element's
+//    place is first + #smaller in the leaf + #equal to its left.
+template <class T, class Less>
+AHK_HDN inline int gs_partition_pivot_ranked(T* a, int first, int last, Less less, uint16_t* posL, uint16_t* posR) {
+  const int mid = first + (last - first) / 2;
+  const int ia = first + 1, ib = mid, ic = last - 1;
+  {
+    const T va = a[ia], vb = a[ib], vc = a[ic];
+    int pick;
+    if (less(va, vb)) pick = less(vb, vc) ? ib : (less(va, vc) ? ic : ia);
+    else pick = less(va, vc) ? ia : (less(vb, vc) ? ic : ib);
+    const T t = a[first];
+    a[first] = a[pick];
+    a[pick] = t;
+  }
+  const T pivot = a[first];
+  int nL = 0, nR = 0;
+  for (int i = first + 1; i < last; i++)
+    if (!less(a[i], pivot)) posL[nL++] = (uint16_t)i;
+  for (int j = last - 1; j > first; j--)
+    if (!less(pivot, a[j])) posR[nR++] = (uint16_t)j;
+  int K = 0;
+  for (int k = 0; k < nL && k < nR; k++) K += posL[k] < posR[k] ? 1 : 0;
+  for (int k = 0; k < K; k++) {
+    const T t = a[posL[k]];
+    a[posL[k]] = a[posR[k]];
+    a[posR[k]] = t;
+  }
+  const int c1 = K < nL ? (int)posL[K] : 0x7fffffff, c2 = K > 0 ? (int)posR[K - 1] : 0x7fffffff;
+  return c1 < c2 ? c1 : c2;
+}
+
+// sorts a[0..n), n <= 65535; posL/posR: n entries each; cutbit: bit i set = a leaf starts at i
+// ((n + 31) / 32 words); tmp: n entries
+template <class T, class Less>
+AHK_HDN inline void gnu_sort_par_ref(T* a, int n, Less less, uint16_t* posL, uint16_t* posR, uint32_t* cutbit, T* tmp) {
+  if (n <= 0) return;
+  for (int w = 0; w < (n + 31) / 32; w++) cutbit[w] = 0;
+  cutbit[0] |= 1u;
+  int depth = 0;
+  for (int t = n; t > 1; t >>= 1) depth++;
+  depth *= 2;
+  int stk[3][64];
+  int sp = 0;
+  stk[0][0] = 0; stk[1][0] = n; stk[2][0] = depth;
+  sp = 1;
+  while (sp > 0) {
+    --sp;
+    int first = stk[0][sp], last = stk[1][sp], d = stk[2][sp];
+    while (last - first > 16) {
+      if (d == 0) {
+        PtrArray<T> arr{a};
+        gs_heapsort(arr, first, last, less);  // (sorted: the final pass leaves it as it is)
+        break;
+      }
+      --d;
+      const int cut = gs_partition_pivot_ranked(a, first, last, less, posL, posR);
+      cutbit[cut >> 5] |= 1u << (cut & 31);
+      stk[0][sp] = cut; stk[1][sp] = last; stk[2][sp] = d;
+      ++sp;
+      last = cut;
+    }
+  }
+  // final pass: a stable sort of every leaf
+  for (int i = 0; i < n; i++) {
+    int f = i;
+    while (!((cutbit[f >> 5] >> (f & 31)) & 1u)) f--;
+    int l = i + 1;
+    while (l < n && !((cutbit[l >> 5] >> (l & 31)) & 1u)) l++;
+    int rank = f;
+    for (int j = f; j < l; j++) rank += (less(a[j], a[i]) || (j < i && !less(a[i], a[j]))) ? 1 : 0;
+    tmp[rank] = a[i];
+  }
+  for (int i = 0; i < n; i++) a[i] = tmp[i];
+}
+
 struct LessHi16 {
   AHK_HDN bool operator()(uint32_t x, uint32_t y) const { return (x >> 16) < (y >> 16); }
 };

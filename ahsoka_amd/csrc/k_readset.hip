@@ -28,6 +28,130 @@ namespace ahk {
 
 
 
+
+// ReadSet::sort() -- the reference's std::sort by first position -- by ONE WAVEFRONT, in the
+// rank-based form of gnusort.h (gnu_sort_par_ref is the sequential statement pinned against
+// std::sort): every partition is two ballot sweeps (positions of the elements not less / not
+// greater than the pivot), a parallel count of the swaps, the swaps themselves and a closed
+// form of the cut; the final insertion sort is a stable rank inside every leaf.  The array and
+// the scratch arrays live in LDS; call with the 64 lanes of one wave, n <= 2048.
+//   a[n], posL[n], posR[n] (u16), cutbit[(n+31)/32] (u32), tmp[n]
+__device__ __forceinline__ int wave_sum_small(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// lanes of ONE wave hand data to each other through LDS between these points: a fence at
+// wavefront scope plus a scheduling barrier (the hardware runs a wave's LDS operations in order)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __noinline__ void wave_sort_hi16(unsigned int* a, int n, int lane, unsigned short* posL, unsigned short* posR,
+                                            unsigned int* cutbit, unsigned int* tmp, int* stk /* [3][64] */) {
+  n = __builtin_amdgcn_readfirstlane(n);
+  if (n <= 1) return;
+  for (int w = lane; w < (n + 31) / 32; w += 64) cutbit[w] = w == 0 ? 1u : 0u;
+  int depth = 0;
+  for (int t = n; t > 1; t >>= 1) depth++;
+  depth *= 2;
+  int sp = 1;
+  if (lane == 0) { stk[0] = 0; stk[64] = n; stk[128] = depth; }
+  const LessHi16 less;
+  while (sp > 0) {
+    --sp;
+    wave_lds_sync();
+    int first = stk[sp], last = stk[64 + sp], d = stk[128 + sp];
+    while (last - first > 16) {
+      if (d == 0) {  // depth limit: heapsort, one lane (adversarial inputs only)
+        if (lane == 0) {
+          PtrArray<unsigned int> arr{a};
+          gs_heapsort(arr, first, last, less);
+        }
+        break;
+      }
+      --d;
+      // median of a[first+1], a[mid], a[last-1] to a[first] (uniform reads, lane 0 swaps)
+      {
+        const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+        const unsigned int va = a[ia], vb = a[ib], vc = a[ic];
+        int pick;
+        if (less(va, vb)) pick = less(vb, vc) ? ib : (less(va, vc) ? ic : ia);
+        else pick = less(va, vc) ? ia : (less(vb, vc) ? ic : ib);
+        const unsigned int vf = a[first], vpk = a[pick];
+        wave_lds_sync();
+        if (lane == 0) {
+          a[first] = vpk;
+          a[pick] = vf;
+        }
+        wave_lds_sync();
+      }
+      const unsigned int pivot = a[first];
+      int nL = 0, nR = 0;
+      for (int i0 = first + 1; i0 < last; i0 += 64) {  // positions not less than the pivot, ascending
+        const int i = i0 + lane;
+        const bool fl = i < last && !less(a[i < last ? i : first], pivot);
+        const unsigned long long mk = __ballot(fl);
+        if (fl) posL[nL + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)i;
+        nL += __popcll(mk);
+      }
+      for (int j0 = last - 1; j0 > first; j0 -= 64) {  // positions not greater than the pivot, descending
+        const int j = j0 - lane;
+        const bool fr = j > first && !less(pivot, a[j > first ? j : first]);
+        const unsigned long long mk = __ballot(fr);
+        if (fr) posR[nR + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)j;
+        nR += __popcll(mk);
+      }
+      wave_lds_sync();
+      const int nmin = nL < nR ? nL : nR;
+      int K = 0;
+      for (int k0 = 0; k0 < nmin; k0 += 64) {
+        const int k = k0 + lane;
+        const bool sw = k < nmin && posL[k < nmin ? k : 0] < posR[k < nmin ? k : 0];
+        K += __popcll(__ballot(sw));
+      }
+      for (int k = lane; k < K; k += 64) {  // disjoint positions
+        const int pl = posL[k], pr = posR[k];
+        const unsigned int t = a[pl];
+        a[pl] = a[pr];
+        a[pr] = t;
+      }
+      wave_lds_sync();
+      const int c1 = K < nL ? (int)posL[K] : 0x7fffffff, c2 = K > 0 ? (int)posR[K - 1] : 0x7fffffff;
+      const int cut = c1 < c2 ? c1 : c2;
+      if (lane == 0) {
+        cutbit[cut >> 5] |= 1u << (cut & 31);
+        stk[sp] = cut;
+        stk[64 + sp] = last;
+        stk[128 + sp] = d;
+      }
+      ++sp;
+      last = cut;
+    }
+  }
+  // final pass: stable rank inside every leaf
+  wave_lds_sync();
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    if (i < n) {
+      int f = i;
+      while (!((cutbit[f >> 5] >> (f & 31)) & 1u)) f--;
+      int l = i + 1;
+      while (l < n && !((cutbit[l >> 5] >> (l & 31)) & 1u)) l++;
+      const unsigned int vi = a[i];
+      int rank = f;
+      for (int j = f; j < l; j++) {
+        const unsigned int vj = a[j];
+        rank += (less(vj, vi) || (j < i && !less(vi, vj))) ? 1 : 0;
+      }
+      tmp[rank] = vi;
+    }
+  }
+  wave_lds_sync();
+  for (int i = lane; i < n; i += 64) a[i] = tmp[i];
+  wave_lds_sync();
+}
+
 __device__ __forceinline__ bool tba_test(const unsigned int* tba, int k) {
   return (tba[k >> 5] >> (k & 31)) & 1u;
 }
@@ -940,21 +1064,26 @@ size_t readset_lds2_bytes(const ReadsetLds2& l) {
 }
 
 // ReadSet::sort() and the permutation of the creation-ordered outputs of k_readset_lds into
-// the sorted order: one wavefront per chain.  Lane 0 runs the reference's std::sort (gnusort.h)
-// on the keys in LDS; then the wave moves names and bit-plane words, lanes = reads (coalesced
-// stores, gathered loads of data that was just written).
-__global__ __launch_bounds__(64) void k_sortperm(DeviceBatch db, const int* __restrict__ list) {
+// the sorted order: one wavefront per chain.  The wave runs the reference's std::sort in its
+// rank-based form (wave_sort_hi16) on the keys in LDS; then it moves names and bit-plane words,
+// lanes = reads (coalesced stores, gathered loads of data that was just written).
+__global__ __launch_bounds__(64) void k_sortperm(DeviceBatch db, const int* __restrict__ list, int maxG) {
   extern __shared__ __align__(16) unsigned long long smem[];
-  unsigned int* srt = (unsigned int*)smem;
+  __shared__ int s_stk[3 * 64];
   const int c = list[blockIdx.x];
   if (db.status[c] != AHSOKA_ST_PHASED) return;
   const ChainMeta m = db.meta[c];
   const int lane = threadIdx.x;
   const int n = db.nfin[c], G = m.G;
+  const int cap = (maxG + 1) & ~1;
+  unsigned int* srt = (unsigned int*)smem;            // [cap]
+  unsigned int* tmp = srt + cap;                      // [cap]
+  unsigned int* cutbit = tmp + cap;                   // [cap/32 + 2]
+  unsigned short* posL = (unsigned short*)(cutbit + ((cap / 32 + 2 + 1) & ~1));  // [cap]
+  unsigned short* posR = posL + cap;                  // [cap]
   for (int i = lane; i < n; i += 64) srt[i] = db.sortkey[m.fr0 + i];
-  __syncthreads();
-  if (lane == 0) gnu_sort(srt, n, LessHi16());
-  __syncthreads();
+  wave_lds_sync();
+  wave_sort_hi16(srt, n, lane, posL, posR, cutbit, tmp, s_stk);
   const int Wp = (db.npos[c] + 63) >> 6;
   for (int i = lane; i < n; i += 64) {
     const int src = (int)(srt[i] & 0xffffu);  // creation rank of the read that sorts to place i
@@ -970,7 +1099,8 @@ __global__ __launch_bounds__(64) void k_sortperm(DeviceBatch db, const int* __re
 void launch_readset_lds(const DeviceBatch& db, const int* list, int count, const ReadsetLds2& l, hipStream_t stream) {
   if (count <= 0) return;
   hipLaunchKernelGGL(k_readset_lds, dim3(count), dim3(kBlock), readset_lds2_bytes(l), stream, db, l, list);
-  hipLaunchKernelGGL(k_sortperm, dim3(count), dim3(64), (size_t)l.maxG * 4 + 16, stream, db, list);
+  const size_t cap = (size_t)((l.maxG + 1) & ~1);  // srt + tmp (u32), cutbit, posL + posR (u16)
+  hipLaunchKernelGGL(k_sortperm, dim3(count), dim3(64), cap * 12 + (cap / 32 + 4) * 4 + 32, stream, db, list, l.maxG);
 }
 
 }  // namespace ahk

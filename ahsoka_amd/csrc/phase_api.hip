@@ -844,4 +844,12 @@ extern "C" int ahsoka_test_introsort_u32(uint32_t* v, int32_t n) {
   gnu_sort(v, n, LessHi16());
   return AHSOKA_OK;
 }
+// the parallelisable form of the same sort (gnusort.h: gnu_sort_par_ref), sequential statement
+extern "C" int ahsoka_test_introsort_par_u32(uint32_t* v, int32_t n) {
+  if (!v || n < 0 || n > 65535) return AHSOKA_E_ARG;
+  std::vector<uint16_t> pl((size_t)n + 1), pr((size_t)n + 1);
+  std::vector<uint32_t> cb((size_t)n / 32 + 2), tmp((size_t)n + 1);
+  gnu_sort_par_ref(v, n, LessHi16(), pl.data(), pr.data(), cb.data(), tmp.data());
+  return AHSOKA_OK;
+}
 extern "C" double ahsoka_test_detlog(double x) { return det_log(x); }

@@ -277,6 +277,8 @@ int64_t ahsoka_synth_truth(const ahsoka_synth_spec* spec, uint8_t* out, int64_t 
 /* test hooks (host-only, no GPU): the device code's re-statement of the
  * libstdc++ introsort, run on the host, so it can be pinned against std::sort */
 int ahsoka_test_introsort_u32(uint32_t* keys_hi16_payload_lo16, int32_t n);
+/* the rank-based (parallelisable) statement of the same sort: must give the same permutation */
+int ahsoka_test_introsort_par_u32(uint32_t* keys_hi16_payload_lo16, int32_t n);
 double ahsoka_test_detlog(double x);
 
 #ifdef __cplusplus

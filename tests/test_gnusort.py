@@ -19,6 +19,10 @@ def both(keys):
     b = v.copy()
     assert capi.lib().ahsoka_test_introsort_u32(a.ctypes.data_as(C.POINTER(C.c_uint32)), n) == 0
     ob.lib().oracle_std_sort_hi16(b.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+    # the rank-based statement of the same algorithm (what the wavefront version computes)
+    c = v.copy()
+    assert capi.lib().ahsoka_test_introsort_par_u32(c.ctypes.data_as(C.POINTER(C.c_uint32)), n) == 0
+    np.testing.assert_array_equal(c, b)
     return a, b
 
 
@@ -79,3 +83,16 @@ def test_heapsort_fallback_is_reached_and_matches():
     keys = np.minimum(keys, 65535)
     a, b = both(keys)
     np.testing.assert_array_equal(a, b)
+
+
+def test_many_random_sizes():
+    """both statements against std::sort on 400 arrays of random length and tie density"""
+    rng = np.random.default_rng(20261005)
+    for _ in range(400):
+        n = int(rng.integers(0, 2049))
+        nkeys = int(rng.choice([1, 2, 3, 7, 40, 300, 65000]))
+        keys = rng.integers(0, nkeys, size=n)
+        if rng.random() < 0.3:
+            keys = np.sort(keys)
+        a, b = both(keys)
+        np.testing.assert_array_equal(a, b)
