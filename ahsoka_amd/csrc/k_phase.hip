@@ -279,7 +279,9 @@ __device__ __forceinline__ void rescan_list(const unsigned short* dlist, int nd,
                                             const unsigned long long* __restrict__ LV, const IcPair* __restrict__ IC,
                                             unsigned long long* bestF, unsigned long long* bestP) {
   for (int di = 2 * wv; di < nd; di += 8) {
-    const int r0 = dlist[di], r1 = di + 1 < nd ? (int)dlist[di + 1] : -1;
+    // (the rows are wave-uniform: as scalars, their address arithmetic runs on the scalar unit)
+    const int r0 = __builtin_amdgcn_readfirstlane((int)dlist[di]);
+    const int r1 = di + 1 < nd ? __builtin_amdgcn_readfirstlane((int)dlist[di + 1]) : -1;
     unsigned long long keys[4];
     rescan_rows2(r0, r1, n, nw, lane, LV, IC, keys);
     if (lane == 0) {
@@ -474,7 +476,18 @@ __device__ __forceinline__ void tri_seg_wide(const int* __restrict__ Wm, int n, 
 __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
                                                      int C, int* __restrict__ qhead) {
   extern __shared__ __align__(16) unsigned long long smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index as a SCALAR: everything derived from it (the row a wave works on, its
+  // share of a list, addresses of wave-uniform loads) then lives in scalar registers and is
+  // computed by the scalar unit; as "threadIdx.x >> 6" the compiler must treat it as divergent
+#ifndef AHK_SCALAR_WV
+#define AHK_SCALAR_WV 1
+#endif
+#if AHK_SCALAR_WV
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+  const int wv = tid >> 6;
+#endif
   const int nmax = lds.nmax;
   unsigned long long* bestF = smem;               // [nmax]  (S4: per-wave key buffers; S6: histograms)
   unsigned long long* bestP = bestF + nmax;       // [nmax]
@@ -522,14 +535,14 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     __syncthreads();
     if (tid == 0) s_chain = atomicAdd(qhead, 1);
     __syncthreads();
-    const int qi = s_chain;
+    const int qi = __builtin_amdgcn_readfirstlane(s_chain);  // (uniform values read from LDS / HBM are made scalar: see wv above)
     if (qi >= C) break;  // every wave of every workgroup reaches this
     const int c = queue[qi];
     if (db.status[c] != AHSOKA_ST_PHASED) continue;
     const ChainMeta m = db.meta[c];
     ChainCtx cx;
-    cx.n = db.nfin[c];
-    cx.P = db.npos[c];
+    cx.n = __builtin_amdgcn_readfirstlane(db.nfin[c]);
+    cx.P = __builtin_amdgcn_readfirstlane(db.npos[c]);
     cx.Wp = (cx.P + 63) >> 6;
     cx.G = m.G;
     cx.cover = db.cover + m.cov0;
@@ -773,6 +786,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           gF = s_rk[k] > gF ? s_rk[k] : gF;
           gP = s_rk[4 + k] > gP ? s_rk[4 + k] : gP;
         }
+        gF = readlane_u64(gF, 0);  // (every lane holds the same two keys: make them scalars)
+        gP = readlane_u64(gP, 0);
         vf = key_val(gF);
         vp = key_val(gP);
         abf = ((unsigned)key_a(gF) << 16) | (unsigned)key_b(gF);
@@ -788,7 +803,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         }
         __syncthreads();
         {
-          rescan_list(dlist, s_nd, wv, lane, n, nw, LV, IC, bestF, bestP);
+          rescan_list(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
         }
         __syncthreads();
 #ifdef AHK_TIMING
@@ -800,9 +815,9 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       if (vf < 0 || vp < 0) break;  // no live edge left (uniform)
       iters++;
       const bool merge = vf >= vp;
-      const int eu = merge ? (int)(abf >> 16) : (int)(abp >> 16);
-      const int ev = merge ? (int)(abf & 0xffff) : (int)(abp & 0xffff);
-      const int cu = cl[eu], cv = cl[ev];
+      const int eu = __builtin_amdgcn_readfirstlane(merge ? (int)(abf >> 16) : (int)(abp >> 16));
+      const int ev = __builtin_amdgcn_readfirstlane(merge ? (int)(abf & 0xffff) : (int)(abp & 0xffff));
+      const int cu = __builtin_amdgcn_readfirstlane((int)cl[eu]), cv = __builtin_amdgcn_readfirstlane((int)cl[ev]);
 
       // ---- fast path: separation of two single reads (9 of 10 iterations) ------
       // The only rewritten pair is (eu,ev); the only induced costs that can change
@@ -950,7 +965,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         Lz[slot] = (unsigned short)z;
       }
       __syncthreads();
-      const int nA = s_cnt[0], nB = s_cnt[1], nFa = s_cnt[2], nFb = s_cnt[3];
+      const int nA = __builtin_amdgcn_readfirstlane(s_cnt[0]), nB = __builtin_amdgcn_readfirstlane(s_cnt[1]);
+      const int nFa = __builtin_amdgcn_readfirstlane(s_cnt[2]), nFb = __builtin_amdgcn_readfirstlane(s_cnt[3]);
       const int nT = nA + nB + nFa + nFb;
 #ifdef AHK_TIMING
       heavy_it = (nA + nFa > 64 && nB + nFb <= 1) || (nB + nFb > 64 && nA + nFa <= 1);
@@ -968,7 +984,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           for (int w0 = 0; w0 < nr; w0 += 8) {
             unsigned long long t[8];
 #pragma unroll
-            for (int c = 0; c < 8; c++) t[c] = (w0 + c < nr) ? NZ[(size_t)Lr[w0 + c] * nw + lane] : 0ull;
+            for (int c = 0; c < 8; c++)
+              t[c] = (w0 + c < nr) ? NZ[(unsigned)(__builtin_amdgcn_readfirstlane((int)Lr[w0 + c < nr ? w0 + c : 0]) * nw + lane)] : 0ull;
 #pragma unroll
             for (int c = 0; c < 8; c++) acc |= t[c];
           }
@@ -1111,7 +1128,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       {
         const unsigned int* items_lds = (const unsigned int*)rowbuf;
         const int cap = 2 * nmax;
-        const int M = s_items;
+        const int M = __builtin_amdgcn_readfirstlane(s_items);
 #ifdef AHK_TIMING
         sumM += M;
         s_items_last = M;
@@ -1152,7 +1169,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             }
           }
           __syncthreads();
-          nh = s_nh;
+          nh = __builtin_amdgcn_readfirstlane(s_nh);
           if (nh > kHeavyMaxItems) {  // enough heavy edges to keep every lane busy: the plain loop does them
             nh = 0;
             heavy = 0u;
@@ -1466,7 +1483,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         if (tid == 0) { s_items = 0; s_nh = 0; }
         AHK_T(6);  // (diagnostic build: weight rewrites vs rescans)
         // rows whose maximum died: exact rescan now (they would tie the next argmax anyway)
-        rescan_list(dlist, s_nd, wv, lane, n, nw, LV, IC, bestF, bestP);
+        rescan_list(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
         AHK_T(7);
       }
       __syncthreads();
@@ -1529,7 +1546,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       if (lane == 0) s_back = base;
     }
     __syncthreads();
-    const int K = s_back;
+    const int K = __builtin_amdgcn_readfirstlane(s_back);
     for (int u = tid; u < n; u += kBlock) {
       const int kc = (int)scratch[nmax + scratch[cl[u]]];
       db.fr_cluster[m.fr0 + u] = kc;
