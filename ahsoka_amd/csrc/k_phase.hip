@@ -65,6 +65,23 @@
 
 namespace ahk {
 
+// Element access with a 32-bit BYTE offset: "base + zext(32-bit offset)" is what the
+// global_load/store saddr form takes (scalar base, one VGPR offset); indexing with
+// base[zext(i)] scales AFTER the extension, i.e. a 64-bit shift and a 64-bit add in the VALU per
+// access.  Offsets stay far below 2^32 (a slot's largest array is n^2 * 16 B = 64 MB).
+#ifndef AHK_AT32
+#define AHK_AT32 1
+#endif
+#if AHK_AT32
+#define AHK_AT(T, base, i) (*(T*)((char*)(base) + (size_t)((unsigned int)(i) * (unsigned int)sizeof(T))))
+#else
+#define AHK_AT(T, base, i) (((T*)(base))[(unsigned int)(i)])
+#endif
+#define WM_AT(i) AHK_AT(int, Wm, i)
+#define IC_AT(i) AHK_AT(IcPair, IC, i)
+#define LV_AT(i) AHK_AT(unsigned long long, LV, i)
+#define NZ_AT(i) AHK_AT(unsigned long long, NZ, i)
+
 constexpr int kLaneExpandMax = AHK_LANE_EXPAND_MAX;  // P3a: bits per word up to which a lane expands its own word
 constexpr int ROLE_NONE = 0, ROLE_A = 1, ROLE_B = 2, ROLE_FA = 3, ROLE_FB = 4;
 
@@ -219,8 +236,8 @@ __device__ __forceinline__ unsigned ic_index(int r, int c, int n) { return (unsi
 // HBM round trip per word, and a row's live edges sit in 2-4 words).
 __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int lane, const unsigned long long* __restrict__ LV,
                                              const IcPair* __restrict__ IC, unsigned long long* keys /* F0 P0 F1 P1 */) {
-  const unsigned long long bm0 = lane < nw ? LV[(unsigned)(r0 * nw + lane)] : 0ull;
-  const unsigned long long bm1 = (r1 >= 0 && lane < nw) ? LV[(unsigned)(r1 * nw + lane)] : 0ull;
+  const unsigned long long bm0 = lane < nw ? LV_AT((unsigned)(r0 * nw + lane)) : 0ull;
+  const unsigned long long bm1 = (r1 >= 0 && lane < nw) ? LV_AT((unsigned)(r1 * nw + lane)) : 0ull;
   unsigned long long todo0 = __ballot(bm0 != 0ull), todo1 = __ballot(bm1 != 0ull);
   unsigned long long kF0 = 0, kP0 = 0, kF1 = 0, kP1 = 0;
   while ((todo0 | todo1) != 0ull) {
@@ -247,7 +264,7 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
       }
       if (l >= 0 && ((w >> lane) & 1ull)) {
         col[c] = (l << 6) + lane;
-        v[c] = IC[ic_index(second[c] ? r1 : r0, col[c], n)];
+        v[c] = IC_AT(ic_index(second[c] ? r1 : r0, col[c], n));
       }
     }
 #pragma unroll
@@ -402,7 +419,7 @@ __device__ __forceinline__ void tri_seg(const int* __restrict__ Wm, int n, int x
     const int w = L[0];
     // (W is symmetric: W[x][w] is read as W[w][x] -- row w is the row every edge of this
     // iteration reads its third edge from, row x would be one more HBM line per row x)
-    const int ov = Wm[(unsigned)(w * n + x)], wb = Wm[(unsigned)(w * n + b)];
+    const int ov = WM_AT((unsigned)(w * n + x)), wb = WM_AT((unsigned)(w * n + b));
     df += icf_term(Nv, wb) - icf_term(ov, wb);
     dp += icp_term(Nv, wb) - icp_term(ov, wb);
     return;
@@ -416,8 +433,8 @@ __device__ __forceinline__ void tri_seg(const int* __restrict__ Wm, int n, int x
     int ovv[4], wbv[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      ovv[c] = Wm[(unsigned)(x * n + wq[c])];
-      wbv[c] = Wm[(unsigned)(wq[c] * n + b)];
+      ovv[c] = WM_AT((unsigned)(x * n + wq[c]));
+      wbv[c] = WM_AT((unsigned)(wq[c] * n + b));
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -432,8 +449,8 @@ __device__ __forceinline__ void tri_seg(const int* __restrict__ Wm, int n, int x
     for (int c = 0; c < kP3bChunk; c++) {
       const bool ok = w0 + c < cnt;
       const int w = ok ? (int)L[w0 + c] : 0;
-      ovv[c] = ok ? Wm[(unsigned)(x * n + w)] : 0;
-      wbv[c] = ok ? Wm[(unsigned)(w * n + b)] : 0;
+      ovv[c] = ok ? WM_AT((unsigned)(x * n + w)) : 0;
+      wbv[c] = ok ? WM_AT((unsigned)(w * n + b)) : 0;
     }
 #pragma unroll
     for (int c = 0; c < kP3bChunk; c++) {
@@ -458,8 +475,8 @@ __device__ __forceinline__ void tri_seg_wide(const int* __restrict__ Wm, int n, 
     int ovv[8], wbv[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-      ovv[c] = Wm[(unsigned)(x * n + wq[c])];
-      wbv[c] = Wm[(unsigned)(wq[c] * n + b)];
+      ovv[c] = WM_AT((unsigned)(x * n + wq[c]));
+      wbv[c] = WM_AT((unsigned)(wq[c] * n + b));
     }
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -517,17 +534,6 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
   unsigned long long* NZ = ws.nz + (size_t)blockIdx.x * ws.nmax * ((ws.nmax + 63) / 64);
   unsigned int* items_glb = ws.items + (size_t)blockIdx.x * ws.nmax * ws.nmax;
   double* rates = ws.rates + (size_t)blockIdx.x * 2 * ws.nmax;
-  unsigned int* sortbuf = ws.sortbuf + (size_t)blockIdx.x * 4 * ws.nmax;
-  int* tp_k = ws.tp_k + (size_t)blockIdx.x * ws.Pmax;
-  int* tp_gcid = ws.tp_gcid + (size_t)blockIdx.x * ws.Pmax * 8;
-  double* tp_cov = ws.tp_cov + (size_t)blockIdx.x * ws.Pmax * 8;
-  int* tp_cons = ws.tp_cons + (size_t)blockIdx.x * ws.Pmax * 8;
-  int* tp_consmap = ws.tp_consmap + (size_t)blockIdx.x * ws.Pmax * 8;
-  int* tp_ntup = ws.tp_ntup + (size_t)blockIdx.x * ws.Pmax;
-  int* tp_tuples = ws.tp_tuples + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
-  double* tp_score = ws.tp_score + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
-  unsigned short* tp_pred = ws.tp_pred + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
-  double* tp_best = ws.tp_best + (size_t)blockIdx.x * ws.Tmax;
 
   const int ploidy = db.ploidy;
 
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             q = quantise_score(t1 + t2);
           }
         }
-        Wm[(unsigned)(i * n + j)] = q;
+        WM_AT((unsigned)(i * n + j)) = q;
         if (m.dump0 >= 0) db.score_dump[m.dump0 + (size_t)i * n + j] = q;
       }
     }
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         int deg = 0, dhi = 0;
         for (int w0 = 0; w0 < n; w0 += 64) {
           const int w = w0 + lane;
-          const bool nz = w < n && Wm[(unsigned)(a * n + w)] != 0;
+          const bool nz = w < n && WM_AT((unsigned)(a * n + w)) != 0;
           const unsigned long long mk = __ballot(nz);
 
           const unsigned long long mh = __ballot(nz && w > a);
@@ -689,8 +695,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           deg += __popcll(mk);
           dhi += __popcll(mh);
           if (lane == 0) {
-            LV[(unsigned)(a * nw + (w0 >> 6))] = mk;
-            NZ[(unsigned)(a * nw + (w0 >> 6))] = mk;
+            LV_AT((unsigned)(a * nw + (w0 >> 6))) = mk;
+            NZ_AT((unsigned)(a * nw + (w0 >> 6))) = mk;
           }
         }
         // lanes = the neighbours b > a.  The row's own weights W[a][w] are wave-uniform:
@@ -701,19 +707,19 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           const int i = i0 + lane;
           const bool act = i < dhi;
           const int b = act ? (int)nhi[i] : a;
-          const int wab = Wm[(unsigned)(a * n + b)];  // (a,a) is 0
+          const int wab = WM_AT((unsigned)(a * n + b));  // (a,a) is 0
           long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
           for (int k0 = 0; k0 < deg; k0 += 64) {
             const int kk = k0 + lane;
             const int nb_l = kk < deg ? (int)nbr[kk] : a;
-            const int wa_l = Wm[(unsigned)(a * n + nb_l)];
+            const int wa_l = WM_AT((unsigned)(a * n + nb_l));
             const int cnt = deg - k0 < 64 ? deg - k0 : 64;
             for (int c0 = 0; c0 < cnt; c0 += 8) {
               int wb[8];
 #pragma unroll
               for (int c = 0; c < 8; c++) {
                 const int w = __builtin_amdgcn_readlane(nb_l, c0 + c);
-                wb[c] = Wm[(unsigned)(w * n + b)];
+                wb[c] = WM_AT((unsigned)(w * n + b));
               }
 #pragma unroll
               for (int c = 0; c < 8; c++) {
@@ -727,8 +733,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             IcPair v;
             v.f = f;
             v.p = p;
-            IC[(unsigned)(a * n + b)] = v;
-            IC[(unsigned)(b * n + a)] = v;
+            IC_AT((unsigned)(a * n + b)) = v;
+            IC_AT((unsigned)(b * n + a)) = v;
             const unsigned long long kf = mkkey(f, a, b), kp = mkkey(p, a, b);
             atomicMax(&bestF[a], kf);
             atomicMax(&bestP[a], kp);
@@ -833,13 +839,13 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         const int x = half ? ev : eu, w = half ? eu : ev;
         unsigned long long lvn = 0ull, nzo = 0ull;
         if (lane < nw) {
-          lvn = LV[(unsigned)(x * nw + lane)];
-          nzo = NZ[(unsigned)(w * nw + lane)];
+          lvn = LV_AT((unsigned)(x * nw + lane));
+          nzo = NZ_AT((unsigned)(w * nw + lane));
         }
-        const int ov = Wm[(unsigned)(eu * n + ev)];  // wave-uniform
+        const int ov = WM_AT((unsigned)(eu * n + ev));  // wave-uniform
         if (lane == (w >> 6)) {
           lvn &= ~(1ull << (w & 63));
-          if (sub == 0) LV[(unsigned)(x * nw + lane)] = lvn;
+          if (sub == 0) LV_AT((unsigned)(x * nw + lane)) = lvn;
         }
         unsigned long long todo = __ballot(lvn != 0ull);
         unsigned long long kF = 0ull, kP = 0ull;
@@ -868,8 +874,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
               if ((wd >> lane) & 1ull) {
                 const int b = (lw[c] << 6) + lane;
                 on[c] = true;
-                icv[c] = IC[ic_index(x, b, n)];
-                if ((cd >> lane) & 1ull) wb[c] = Wm[(unsigned)(w * n + b)];
+                icv[c] = IC_AT(ic_index(x, b, n));
+                if ((cd >> lane) & 1ull) wb[c] = WM_AT((unsigned)(w * n + b));
               }
             }
           }
@@ -883,8 +889,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             if (df != 0 || dp != 0) {
               ic.f += df;
               ic.p += dp;
-              IC[ic_index(x, b, n)] = ic;
-              IC[ic_index(b, x, n)] = ic;
+              IC_AT(ic_index(x, b, n)) = ic;
+              IC_AT(ic_index(b, x, n)) = ic;
             }
             const unsigned long long r1 = mkkey(ic.f, x, b), r2 = mkkey(ic.p, x, b);
             if (df != 0 || dp != 0) {
@@ -904,7 +910,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           const unsigned long long a1 = s_rk[2 * tid], a2 = s_rk[2 * tid + 1], b1 = s_rk[4 + 2 * tid], b2 = s_rk[4 + 2 * tid + 1];
           bestF[xr] = a1 > a2 ? a1 : a2;
           bestP[xr] = b1 > b2 ? b1 : b2;
-          Wm[(unsigned)(xr * n + (tid ? eu : ev))] = W_FORB;  // every wave has read the old weight by now
+          WM_AT((unsigned)(xr * n + (tid ? eu : ev))) = W_FORB;  // every wave has read the old weight by now
         }
         __syncthreads();
 #ifdef AHK_TIMING
@@ -927,7 +933,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           if (cz == cu) r = ROLE_A;
           else if (cz == cv) r = ROLE_B;
           else if (merge) {
-            const bool fa = Wm[(unsigned)(eu * n + z)] == W_FORB, fb = Wm[(unsigned)(ev * n + z)] == W_FORB;
+            const bool fa = WM_AT((unsigned)(eu * n + z)) == W_FORB, fb = WM_AT((unsigned)(ev * n + z)) == W_FORB;
             if (fa && !fb) r = ROLE_FA;
             if (fb && !fa) r = ROLE_FB;
           }
@@ -985,7 +991,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             unsigned long long t[8];
 #pragma unroll
             for (int c = 0; c < 8; c++)
-              t[c] = (w0 + c < nr) ? NZ[(unsigned)(__builtin_amdgcn_readfirstlane((int)Lr[w0 + c < nr ? w0 + c : 0]) * nw + lane)] : 0ull;
+              t[c] = (w0 + c < nr) ? NZ_AT((unsigned)(__builtin_amdgcn_readfirstlane((int)Lr[w0 + c < nr ? w0 + c : 0]) * nw + lane)) : 0ull;
 #pragma unroll
             for (int c = 0; c < 8; c++) acc |= t[c];
           }
@@ -1036,8 +1042,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         int x_nx = row_of(wv * RP + slot);
         unsigned long long lv_nx = 0ull, nz_nx = 0ull;
         if (x_nx >= 0 && wordok) {
-          lv_nx = LV[(unsigned)(x_nx * nw + kw)];
-          nz_nx = NZ[(unsigned)(x_nx * nw + kw)];
+          lv_nx = LV_AT((unsigned)(x_nx * nw + kw));
+          nz_nx = NZ_AT((unsigned)(x_nx * nw + kw));
         }
         for (int xi0 = wv * RP; xi0 < nT; xi0 += 4 * RP) {
           const int xi = xi0 + slot;
@@ -1047,8 +1053,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           lv_nx = 0ull;
           nz_nx = 0ull;
           if (x_nx >= 0 && wordok) {
-            lv_nx = LV[(unsigned)(x_nx * nw + kw)];
-            nz_nx = NZ[(unsigned)(x_nx * nw + kw)];
+            lv_nx = LV_AT((unsigned)(x_nx * nw + kw));
+            nz_nx = NZ_AT((unsigned)(x_nx * nw + kw));
           }
           // the role of x follows from which list it came from
           const int rx = xi < nA ? ROLE_A : xi < nA + nB ? ROLE_B : xi < nA + nB + nFa ? ROLE_FA : ROLE_FB;
@@ -1069,8 +1075,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           if (x >= 0 && wordok) {
             const unsigned long long lvn = lvw & ~D;
             const unsigned long long nzn = nzw | D;
-            if (lvn != lvw) LV[(unsigned)(x * nw + kw)] = lvn;
-            if (nzn != nzw) NZ[(unsigned)(x * nw + kw)] = nzn;
+            if (lvn != lvw) LV_AT((unsigned)(x * nw + kw)) = lvn;
+            if (nzn != nzw) NZ_AT((unsigned)(x * nw + kw)) = nzn;
             const int xw = x >> 6;
             const unsigned long long low = kw < xw ? ~0ull : (kw == xw ? ((1ull << (x & 63)) - 1ull) : 0ull);
             // columns with a non-zero third edge to some rewritten neighbour of x
@@ -1188,7 +1194,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           // memory system can deliver them for this access pattern, so the entry (one 128-B
           // line for 16 useful bytes) is loaded only once the delta is known to be non-zero.
 #if !AHK_IC_LATE
-          IcPair ic = IC[ici];
+          IcPair ic = IC_AT(ici);
 #endif
           long long df = 0, dp = 0;
 #if defined(AHK_TIMING) && AHK_TIMING > 1
@@ -1219,8 +1225,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
                 const int wi = w0 + c;
                 const int w = wi < n1 ? L1[wi] : (wi < nc ? L2[wi - n1] : -1);
                 ws4[c] = w;
-                ov4[c] = w >= 0 ? Wm[(unsigned)(x * n + w)] : 0;
-                wb4[c] = w >= 0 ? Wm[(unsigned)(w * n + b)] : 0;
+                ov4[c] = w >= 0 ? WM_AT((unsigned)(x * n + w)) : 0;
+                wb4[c] = w >= 0 ? WM_AT((unsigned)(w * n + b)) : 0;
               }
 #pragma unroll
               for (int c = 0; c < kP3bChunk; c++) {
@@ -1251,8 +1257,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
                 const int rw = role[w];
                 if (w == x || in_s(rx, rw, merge)) continue;  // (x,w) changes too: counted above
                 const int Nv = new_w(rb, rw, merge);
-                const int ov = Wm[(unsigned)(w * n + b)];
-                const int xw = Wm[(unsigned)(x * n + w)];
+                const int ov = WM_AT((unsigned)(w * n + b));
+                const int xw = WM_AT((unsigned)(x * n + w));
                 df += icf_term(Nv, xw) - icf_term(ov, xw);
                 dp += icp_term(Nv, xw) - icp_term(ov, xw);
               }
@@ -1263,12 +1269,12 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
 #endif
           if (df == 0 && dp == 0) continue;
 #if AHK_IC_LATE
-          IcPair ic = IC[ici];
+          IcPair ic = IC_AT(ici);
 #endif
           ic.f += df;
           ic.p += dp;
-          IC[ici] = ic;
-          IC[ic_index(b, x, n)] = ic;
+          IC_AT(ici) = ic;
+          IC_AT(ic_index(b, x, n)) = ic;
 #ifdef AHK_TIMING
           atomicAdd(&s_chg, 1);
 #endif
@@ -1340,11 +1346,11 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
               const unsigned int it = hl[r0 + hh];
               const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
               const unsigned ici = ic_index(x, b, n);
-              IcPair ic = IC[ici];
+              IcPair ic = IC_AT(ici);
               ic.f += df;
               ic.p += dp;
-              IC[ici] = ic;
-              IC[ic_index(b, x, n)] = ic;
+              IC_AT(ici) = ic;
+              IC_AT(ic_index(b, x, n)) = ic;
 #ifdef AHK_TIMING
               atomicAdd(&s_chg, 1);
 #endif
@@ -1367,14 +1373,14 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         // Sums are exact integers: a 64-bit DPP reduction, applied by lane 0.  (The bitmap row
         // of the wave's next edge is requested before the current edge is worked on.)
         unsigned long long nz_nx = 0ull;
-        if (wv < nh && lane < nw) nz_nx = NZ[(unsigned)((int)(hl[wv] & 0xfffu) * nw + lane)];
+        if (wv < nh && lane < nw) nz_nx = NZ_AT((unsigned)((int)(hl[wv] & 0xfffu) * nw + lane));
         for (int h = wv; h < nh; h += 4) {
           const unsigned int it = hl[h];
           const int rx = (int)(it >> 28);
           const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
           const unsigned long long nzw = nz_nx;
           nz_nx = 0ull;
-          if (h + 4 < nh && lane < nw) nz_nx = NZ[(unsigned)((int)(hl[h + 4] & 0xfffu) * nw + lane)];
+          if (h + 4 < nh && lane < nw) nz_nx = NZ_AT((unsigned)((int)(hl[h + 4] & 0xfffu) * nw + lane));
           long long df = 0, dp = 0;
 #pragma unroll
           for (int sg = 0; sg < 2; sg++) {
@@ -1402,8 +1408,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
 #pragma unroll
               for (int c = 0; c < 2; c++)
                 if (in[c]) {
-                  wb[c] = Wm[(unsigned)(b * n + w[c])];
-                  ov[c] = Wm[(unsigned)(x * n + w[c])];
+                  wb[c] = WM_AT((unsigned)(b * n + w[c]));
+                  ov[c] = WM_AT((unsigned)(x * n + w[c]));
                 }
 #pragma unroll
               for (int c = 0; c < 2; c++) {
@@ -1422,11 +1428,11 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           dp = wave_sum_i64(dp);
           if (lane == 0 && (df != 0 || dp != 0)) {
             const unsigned ici = ic_index(x, b, n);
-            IcPair ic = IC[ici];
+            IcPair ic = IC_AT(ici);
             ic.f += df;
             ic.p += dp;
-            IC[ici] = ic;
-            IC[ic_index(b, x, n)] = ic;
+            IC_AT(ici) = ic;
+            IC_AT(ic_index(b, x, n)) = ic;
 #ifdef AHK_TIMING
             atomicAdd(&s_chg, 1);
 #endif
@@ -1464,8 +1470,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
               y = listFa[yi];
               N = W_FORB;
             }
-            Wm[(unsigned)(x * n + y)] = N;
-            Wm[(unsigned)(y * n + x)] = N;
+            WM_AT((unsigned)(x * n + y)) = N;
+            WM_AT((unsigned)(y * n + x)) = N;
           }
         }
         if (merge) {
@@ -1527,6 +1533,19 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     if (lds.stop_after == 3) continue;
 #endif
 
+    // (the per-slot tables of S6/S7 are addressed only from here on: computed here, their
+    // pointers do not occupy scalar registers during S5, which spills them as it is)
+    unsigned int* sortbuf = ws.sortbuf + (size_t)blockIdx.x * 4 * ws.nmax;
+    int* tp_k = ws.tp_k + (size_t)blockIdx.x * ws.Pmax;
+    int* tp_gcid = ws.tp_gcid + (size_t)blockIdx.x * ws.Pmax * 8;
+    double* tp_cov = ws.tp_cov + (size_t)blockIdx.x * ws.Pmax * 8;
+    int* tp_cons = ws.tp_cons + (size_t)blockIdx.x * ws.Pmax * 8;
+    int* tp_consmap = ws.tp_consmap + (size_t)blockIdx.x * ws.Pmax * 8;
+    int* tp_ntup = ws.tp_ntup + (size_t)blockIdx.x * ws.Pmax;
+    int* tp_tuples = ws.tp_tuples + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
+    double* tp_score = ws.tp_score + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
+    unsigned short* tp_pred = ws.tp_pred + (size_t)blockIdx.x * ws.Pmax * ws.Tmax;
+    double* tp_best = ws.tp_best + (size_t)blockIdx.x * ws.Tmax;
     // ---- clusters: ordered by smallest member ------------------------------
     // (bestF is free now: reuse as scratch)
     unsigned int* scratch = (unsigned int*)bestF;  // [4*nmax] u32 available
