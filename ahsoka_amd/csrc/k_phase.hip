@@ -199,7 +199,34 @@ __device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v)
   const unsigned long long t = ((unsigned long long)hi << 32) | lo;
   return t > v ? t : v;
 }
+#ifndef AHK_MAX_SPLIT
+#define AHK_MAX_SPLIT 1
+#endif
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned int dpp_max_step32(unsigned int v) {
+  const unsigned int t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
+  return t > v ? t : v;  // (the compiler folds the DPP move into v_max_u32: one instruction per step)
+}
+__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
+  v = dpp_max_step32<0x111, 0xf>(v);
+  v = dpp_max_step32<0x112, 0xf>(v);
+  v = dpp_max_step32<0x114, 0xf>(v);
+  v = dpp_max_step32<0x118, 0xf>(v);
+  v = dpp_max_step32<0x142, 0xa>(v);
+  v = dpp_max_step32<0x143, 0xc>(v);
+  return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#if AHK_MAX_SPLIT
+  // a 64-bit maximum as two 32-bit ones: the high words first, then the low words of the lanes
+  // that hold the maximal high word.  A 64-bit step costs two DPP moves, a 64-bit compare and
+  // two selects; a 32-bit step is ONE v_max_u32 with a DPP operand -- 16 instead of 36
+  // instructions per reduction, and the reductions are a third of a fast iteration.
+  const unsigned int hi = (unsigned int)(v >> 32), lo = (unsigned int)v;
+  const unsigned int mh = wave_max_u32(hi);
+  const unsigned int ml = wave_max_u32(hi == mh ? lo : 0u);
+  return ((unsigned long long)mh << 32) | ml;
+#else
   v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
   v = dpp_max_step<0x112, 0xf>(v);  // row_shr:2
   v = dpp_max_step<0x114, 0xf>(v);  // row_shr:4
@@ -207,6 +234,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
   v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
   return readlane_u64(v, 63);
+#endif
 }
 
 // is the pair (role r1, role r2) rewritten by this iteration, and to what:
