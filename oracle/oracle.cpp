@@ -26,6 +26,8 @@
  */
 #include "../include/ahsoka_phase.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cassert>
 #include <chrono>
@@ -403,6 +405,24 @@ struct ClusterEditing {
       }
       if (fu < 0 || pu < 0) break;  // no live edge left
       iterations++;
+#ifdef ORACLE_CE_TRACE
+      {  // experiment support (tools/ce_pair_stats.py): the decision and the runner-up among the icp row maxima
+        static FILE* tf = getenv("ORACLE_CE_TRACE") ? fopen(getenv("ORACLE_CE_TRACE"), "w") : nullptr;
+        if (tf) {
+          int64_t v2 = -1; int a2 = -1, b2 = -1;
+          for (int u = 0; u < n; u++) {
+            if (bestP[u].col < 0) continue;
+            int a = std::min(u, bestP[u].col), b = std::max(u, bestP[u].col);
+            if (a == pu && b == pv) continue;
+            if (bestP[u].val > v2 || (bestP[u].val == v2 && (a < a2 || (a == a2 && b < b2)))) { v2 = bestP[u].val; a2 = a; b2 = b; }
+          }
+          const bool mg = vf >= vp;
+          const int u = mg ? fu : pu, v = mg ? fv : pv;
+          fprintf(tf, "%d %d %d %d %d %lld %lld %d %d %lld\n", mg ? 1 : 0, u, v, (int)members[clique[u]].size(), (int)members[clique[v]].size(),
+                  (long long)vf, (long long)vp, a2, b2, (long long)v2);
+        }
+      }
+#endif
       if (vf >= vp) merge(fu, fv);
       else forbid(pu, pv);
     }

@@ -20,6 +20,7 @@
  * headers and is unbuildable here), a C entry point ref_is_subset().
  */
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <functional>
 #include <iostream>
@@ -53,12 +54,25 @@ int main(int argc, char** argv) {
     fprintf(stderr, "usage: ref_dump <gfa> <gaf>\n");
     return 2;
   }
-  // same sequence as src/polyassembly.cpp:82-140
+  // same sequence as src/polyassembly.cpp:82-140; REF_TIME=1: only time the four steps
+  // (the CPU baseline of the ingest rows f1/f2/f4, tools/ingest_bench.py) and exit
+  const bool timing = getenv("REF_TIME") != nullptr;
+  auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   Graph graph = Graph::ReadGraph(argv[1]);
+  const double t1 = now();
   graph.findBubbles();
+  const double t2 = now();
   AlignmentReader reader;
   reader.readAlignmentfile(argv[2], graph);
+  const double t3 = now();
   auto pathToAlleles = ChainsToReadsetDetailed(graph);
+  const double t4 = now();
+  if (timing) {
+    printf("{\"read_graph_s\": %.4f, \"find_bubbles_s\": %.4f, \"read_alignments_s\": %.4f, \"allele_paths_s\": %.4f, \"total_s\": %.4f}\n", t1 - t0, t2 - t1,
+           t3 - t2, t4 - t3, t4 - t0);
+    return 0;
+  }
   vector<pair<int, int>> size_sorting;
   for (auto& chainmap : pathToAlleles) size_sorting.emplace_back(chainmap.second.size(), chainmap.first);
   sort(begin(size_sorting), end(size_sorting), greater<>());
