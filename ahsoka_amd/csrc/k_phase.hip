@@ -49,6 +49,19 @@
 #define AHK_T(slot) do {} while (0)
 #endif
 
+// Diagnostic build only (-DAHK_FTRACE): per wave, cycles between consecutive marks inside the
+// argmax and the single-read separation; workgroup 0 prints the sums for its first chain.
+#ifdef AHK_FTRACE
+#define AHK_F(slot)                                                               \
+  do {                                                                            \
+    const long long _t = (long long)__builtin_amdgcn_s_memtime();                 \
+    if (lane == 0) atomicAdd(&s_ft[wv][slot], (unsigned long long)(_t - ftl));    \
+    ftl = _t;                                                                     \
+  } while (0)
+#else
+#define AHK_F(slot) do {} while (0)
+#endif
+
 // tuning switches (tools/variants.sh builds and benches combinations on one box)
 #ifndef AHK_P3B_SINGLE
 #define AHK_P3B_SINGLE 1
@@ -235,6 +248,39 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
   return readlane_u64(v, 63);
 #endif
+}
+
+// fold_key of the keys (c1 into bestF[x], c2 into bestP[x]) of every active lane, for lanes that
+// mostly share their row x (consecutive edges of a row): 64 LDS atomics on one address take
+// turns, a few hundred cycles each wave instruction, so the lanes of a row are combined first
+// (one maximum, one "a stored maximum went down" flag, applied by one lane).  Any order of the
+// single updates gives a valid state (an upper bound per row, exact unless marked stale), and so
+// does this.  Up to four rows per call are combined; lanes of further rows update on their own.
+__device__ __forceinline__ void fold_rows_grouped(bool act, int x, unsigned long long c1, unsigned long long c2, unsigned long long* bestF,
+                                                  unsigned long long* bestP, int lane) {
+  unsigned long long rem = __ballot(act);
+#pragma unroll 1
+  for (int g = 0; g < 4 && rem != 0ull; g++) {
+    const int l0 = __builtin_ctzll(rem);
+    const int xs = __builtin_amdgcn_readlane(x, l0);
+    const bool mine = act && x == xs;
+    const unsigned long long kF0 = bestF[xs], kP0 = bestP[xs];
+    const unsigned long long mF = wave_max_u64(mine ? c1 : 0ull), mP = wave_max_u64(mine ? c2 : 0ull);
+    const bool stF = mine && ((kF0 ^ c1) & kPairMask) == 0ull && c1 < (kF0 & ~kStale);
+    const bool stP = mine && ((kP0 ^ c2) & kPairMask) == 0ull && c2 < (kP0 & ~kStale);
+    const unsigned long long bF = __ballot(stF), bP = __ballot(stP);
+    if (lane == l0) {
+      if (bF != 0ull) atomicOr(&bestF[xs], kStale);
+      atomicMax(&bestF[xs], mF);
+      if (bP != 0ull) atomicOr(&bestP[xs], kStale);
+      atomicMax(&bestP[xs], mP);
+    }
+    rem &= ~__ballot(mine);
+  }
+  if (act && ((rem >> lane) & 1ull)) {
+    fold_key(&bestF[x], c1);
+    fold_key(&bestP[x], c2);
+  }
 }
 
 // is the pair (role r1, role r2) rewritten by this iteration, and to what:
@@ -547,12 +593,18 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
   unsigned long long* rmask = (unsigned long long*)(multiw + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][32] role masks per 64-column word
   unsigned long long* rolenz = rmask + 4 * 32;             // [4][32] OR of the members' nz-rows
   unsigned char* role = (unsigned char*)(rolenz + 4 * 32);  // [nmax]
-  __shared__ int s_chain, s_cnt[4], s_nd, s_items, s_nh;
+  int* wrow = (int*)(role + nmax);                         // [nmax] weights of a single read's row (see "staged row")
+  __shared__ int s_chain, s_cnt[4], s_nd, s_items, s_nh, s_nslow;
   __shared__ unsigned short s_pref[4][32];
 #ifdef AHK_TIMING
   __shared__ int s_chg;
 #endif
   __shared__ unsigned long long s_rk[16];
+#ifdef AHK_FTRACE
+  __shared__ unsigned long long s_ft[4][16];
+  long long ftl = 0;
+  bool ft_first = blockIdx.x == 0;
+#endif
   __shared__ int s_asc[4][8];
   __shared__ int s_back;
 
@@ -774,7 +826,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     }
     for (int u = tid; u < (n + 31) / 32; u += kBlock) multiw[u] = 0;
     if (tid < 4) s_cnt[tid] = 0;
-    if (tid == 0) { s_nd = 0; s_items = 0; s_nh = 0; }
+    if (tid == 0) { s_nd = 0; s_items = 0; s_nh = 0; s_nslow = 0; }
     __syncthreads();
 #ifdef AHK_DIAG
     if (lds.stop_after == 2) continue;
@@ -782,12 +834,20 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
 
     // ================= S5 main loop ========================================
     long long iters = 0;
+#ifdef AHK_FTRACE
+    if (tid < 64) s_ft[tid >> 4][tid & 15] = 0ull;
+    __syncthreads();
+    long long ft_nfast = 0, ft_nother = 0;
+    ftl = (long long)__builtin_amdgcn_s_memtime();
+#endif
 #ifdef AHK_TIMING
     int s_items_last = 0;
     if (tid == 0) s_chg = 0;
     long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)clock64(), nretry = 0, nresc = 0, sumT = 0, sumM = 0, sumW = 0;
     long long hM[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hMc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hT[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hTc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, titer = tlast, nmerge = 0, sumnd = 0, nfast = 0;
     long long tacc2[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, nheavy = 0;
+    long long pl_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long pcat_c[4] = {0, 0, 0, 0}, pcat_n[4] = {0, 0, 0, 0}, pcat_m[4] = {0, 0, 0, 0}, pcat_f[4] = {0, 0, 0, 0};
     bool heavy_it = false;
     long long h2[32], h2c[32], h2m[32];
     for (int q = 0; q < 32; q++) { h2[q] = 0; h2c[q] = 0; h2m[q] = 0; }
@@ -809,12 +869,15 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           gF = k1 > gF ? k1 : gF;
           gP = k2 > gP ? k2 : gP;
         }
+        AHK_F(0);  // (since the end of the previous iteration: the LDS scan)
         gF = wave_max_u64(gF);
         gP = wave_max_u64(gP);
         if (lane == 0) {
           s_rk[wv] = gF; s_rk[4 + wv] = gP;
         }
+        AHK_F(1);
         __syncthreads();
+        AHK_F(2);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           gF = s_rk[k] > gF ? s_rk[k] : gF;
@@ -862,6 +925,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       // falls out of the same pass (the general path would queue both rows for a
       // rescan: their maximum is the edge that dies).  Two dependent HBM round
       // trips per iteration instead of about ten.
+      AHK_F(3);
       if (!merge && !(((multiw[eu >> 5] >> (eu & 31)) | (multiw[ev >> 5] >> (ev & 31))) & 1u)) {
         const int half = wv >> 1, sub = wv & 1;
         const int x = half ? ev : eu, w = half ? eu : ev;
@@ -877,6 +941,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         }
         unsigned long long todo = __ballot(lvn != 0ull);
         unsigned long long kF = 0ull, kP = 0ull;
+        AHK_F(4);
         // this wave takes the live words of even (sub 0) / odd (sub 1) rank, kFastBatch per trip
         while (todo != 0ull) {
           int lw[kFastBatch];
@@ -929,10 +994,13 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             kP = r2 > kP ? r2 : kP;
           }
         }
+        AHK_F(5);
         kF = wave_max_u64(kF);
         kP = wave_max_u64(kP);
         if (lane == 0) { s_rk[wv] = kF; s_rk[4 + wv] = kP; }
+        AHK_F(6);
         __syncthreads();
+        AHK_F(7);
         if (tid < 2) {
           const int xr = tid ? ev : eu;
           const unsigned long long a1 = s_rk[2 * tid], a2 = s_rk[2 * tid + 1], b1 = s_rk[4 + 2 * tid], b2 = s_rk[4 + 2 * tid + 1];
@@ -941,6 +1009,10 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           WM_AT((unsigned)(xr * n + (tid ? eu : ev))) = W_FORB;  // every wave has read the old weight by now
         }
         __syncthreads();
+        AHK_F(8);
+#ifdef AHK_FTRACE
+        ft_nfast++;
+#endif
 #ifdef AHK_TIMING
         AHK_T(11);
         nfast++;
@@ -948,6 +1020,18 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
 #endif
         continue;
       }
+#ifdef AHK_FTRACE
+      ft_nother++;
+#endif
+
+      // ---- staged row: when one side of the decision is a single read rs (96 % of the
+      // iterations that get here: a read joining or leaving a clique), every edge (y,b) of the
+      // other side's rows y has the one triangle (y,rs,b), whose two other edges W[rs][y] and
+      // W[rs][b] both sit in row rs.  That row goes to LDS now; P3b then prices those edges
+      // (thousands per iteration, 4 % of them change) without touching HBM.
+      const int rs = __builtin_amdgcn_readfirstlane(!((multiw[eu >> 5] >> (eu & 31)) & 1u) ? eu : (!((multiw[ev >> 5] >> (ev & 31)) & 1u) ? ev : -1));
+      if (rs >= 0)
+        for (int z = tid; z < n; z += kBlock) wrow[z] = WM_AT((unsigned)(rs * n + z));
 
       // ---- P2: roles, member lists and per-word role masks --------------------
       // (s_cnt was zeroed before the last barrier).  rmask[R][k] has bit c set iff
@@ -1185,37 +1269,19 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         }
         unsigned int* hl = items_glb + (size_t)(ws.nmax * ws.nmax / 2);  // (overflow items use the first half at most)
         int nh = 0;
-        if (heavy != 0u) {  // uniform
-          for (int i0 = 0; i0 < M; i0 += kBlock) {
-            const int i = i0 + tid;
-            unsigned int it = 0u;
-            bool hv = false;
-            if (i < M) {
-              it = i < cap ? items_lds[i] : items_glb[i - cap];
-              hv = ((heavy >> (it >> 28)) & 1u) && ((it >> 24) & 7u) == (unsigned)ROLE_NONE;
-            }
-            const unsigned long long mk = __ballot(hv);
-            if (mk != 0ull) {
-              int base = 0;
-              if (lane == 0) base = atomicAdd(&s_nh, __popcll(mk));
-              base = __builtin_amdgcn_readlane(base, 0);
-              if (hv) hl[base + mask_rank(mk)] = it;
-            }
-          }
-          __syncthreads();
-          nh = __builtin_amdgcn_readfirstlane(s_nh);
-          if (nh > kHeavyMaxItems) {  // enough heavy edges to keep every lane busy: the plain loop does them
-            nh = 0;
-            heavy = 0u;
-          }
+#endif
+#if defined(AHK_TIMING) && AHK_TIMING == 1
+        AHK_T(8);  // (level 1: "decode" = heavy-list building, "tri" = the plain loop, P3b = the heavy pass)
+#endif
+        // Edges priced from the staged row (rb == NONE, the row's only member list is {rs}):
+        // roles whose rows qualify
+        unsigned int ldsrole = 0u;
+        if (rs >= 0) {
+          if (rs == eu) ldsrole = (nFa == 0 ? 1u << ROLE_B : 0u) | (1u << ROLE_FB);
+          else ldsrole = (nFb == 0 ? 1u << ROLE_A : 0u) | (1u << ROLE_FA);
         }
-#endif
-        for (int i = tid; i < M; i += kBlock) {
-          const unsigned int it = i < cap ? items_lds[i] : items_glb[i - cap];
-          const int rx = (int)(it >> 28), rb = (int)((it >> 24) & 7u);
-#if AHK_HEAVY
-          if (((heavy >> rx) & 1u) && rb == ROLE_NONE) continue;  // one wave per such edge, below
-#endif
+        // any other edge: its triangles from HBM, applied at once
+        auto plain_item = [&](const unsigned int it, const int rx, const int rb) {
           const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
           const unsigned ici = ic_index(x, b, n);
           // Only ~4 % of the candidates change.  The kernel moves HBM lines at the rate the
@@ -1295,7 +1361,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
 #if defined(AHK_TIMING) && AHK_TIMING > 1
           AHK_T(9);
 #endif
-          if (df == 0 && dp == 0) continue;
+          if (df == 0 && dp == 0) return;
 #if AHK_IC_LATE
           IcPair ic = IC_AT(ici);
 #endif
@@ -1303,9 +1369,6 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           ic.p += dp;
           IC_AT(ici) = ic;
           IC_AT(ic_index(b, x, n)) = ic;
-#ifdef AHK_TIMING
-          atomicAdd(&s_chg, 1);
-#endif
           // fold the new value into both row maxima; a maximum that sat on this
           // edge and went down is now only an upper bound -> mark the row stale
           {
@@ -1318,7 +1381,169 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
 #if defined(AHK_TIMING) && AHK_TIMING > 1
           AHK_T(10);
 #endif
+        };
+        // Staged-row edges are priced from LDS; the few that change are parked in a per-wave list
+        // (rmask/rolenz are dead after P3a: 128 entries per wave) and applied 64 at a time, so the
+        // induced-cost round trip is paid once per 64 changes instead of once per loop trip.
+        unsigned int* pend = (unsigned int*)rmask + wv * 128;
+        int npend = 0;
+        auto staged_delta = [&](const unsigned int it, long long& df, long long& dp) {
+          const int rx = (int)(it >> 28);
+          const int ov = wrow[(it >> 12) & 0xfffu], wb = wrow[it & 0xfffu];
+          if (merge && (rx == ROLE_A || rx == ROLE_B)) {
+            df = (long long)icf_term(W_PERM, wb) - (long long)icf_term(ov, wb);
+            dp = (long long)icp_term(W_PERM, wb) - (long long)icp_term(ov, wb);
+          } else {
+            df = (long long)icf_term(W_FORB, wb) - (long long)icf_term(ov, wb);
+            dp = (long long)icp_term(W_FORB, wb) - (long long)icp_term(ov, wb);
+          }
+        };
+        auto apply_pending = [&](const int cnt) {
+          const bool act = lane < cnt;
+          int x = 0;
+          unsigned long long c1 = 0ull, c2 = 0ull;
+          if (act) {
+            const unsigned int it = pend[lane];
+            x = (int)((it >> 12) & 0xfffu);
+            const int b = (int)(it & 0xfffu);
+            long long df, dp;
+            staged_delta(it, df, dp);
+            const unsigned ici = ic_index(x, b, n);
+            IcPair ic = IC_AT(ici);
+            ic.f += df;
+            ic.p += dp;
+            IC_AT(ici) = ic;
+            IC_AT(ic_index(b, x, n)) = ic;
+            c1 = mkkey(ic.f, x, b);
+            c2 = mkkey(ic.p, x, b);
+            fold_key(&bestF[b], c1);
+            fold_key(&bestP[b], c2);
+          }
+          fold_rows_grouped(act, x, c1, c2, bestF, bestP, lane);  // (consecutive entries are edges of one row)
+        };
+        // Pass A (only when some role is staged or heavy): every item is classified -- heavy edges
+        // to hl, staged-row edges priced on the spot, anything else to a list of its own (slow,
+        // growing down from the end of hl's region: each item lands in one list at most).  A trip
+        // is a few dozen instructions, so the items that overflowed to HBM are requested four
+        // trips ahead.  Pass B prices what is left, one lane per edge with its triangles from HBM:
+        // the whole item list when nothing is staged or heavy, else the slow list, plus hl when it
+        // turns out long enough to keep every lane busy that way.
+        const bool classified = ldsrole != 0u || heavy != 0u;  // uniform
+        unsigned int* slow_end = items_glb + (size_t)ws.nmax * ws.nmax;  // slow item k at slow_end[-1 - k]
+        int nslow = 0;
+        if (classified) {
+          auto classify = [&](const unsigned int it, const bool valid) {
+            bool chg = false, hv = false, sl = false;
+            if (valid) {
+              const int rx = (int)(it >> 28), rb = (int)((it >> 24) & 7u);
+              hv = ((heavy >> rx) & 1u) && rb == ROLE_NONE;
+              if (!hv) {
+                if (((ldsrole >> rx) & 1u) && rb == ROLE_NONE) {
+                  long long df, dp;
+                  staged_delta(it, df, dp);
+                  chg = df != 0 || dp != 0;
+                } else {
+                  sl = true;
+                }
+              }
+            }
+            const unsigned long long mk = __ballot(hv), ms = __ballot(sl), cm = __ballot(chg);
+            if (mk != 0ull) {
+              int base = 0;
+              if (lane == 0) base = atomicAdd(&s_nh, __popcll(mk));
+              base = __builtin_amdgcn_readlane(base, 0);
+              if (hv) hl[base + mask_rank(mk)] = it;
+            }
+            if (ms != 0ull) {
+              int base = 0;
+              if (lane == 0) base = atomicAdd(&s_nslow, __popcll(ms));
+              base = __builtin_amdgcn_readlane(base, 0);
+              if (sl) slow_end[-1 - (base + mask_rank(ms))] = it;
+            }
+            if (cm != 0ull) {  // wave-uniform
+#ifdef AHK_TIMING
+              if (lane == 0) atomicAdd(&s_chg, __popcll(cm));
+#endif
+              if (chg) pend[npend + mask_rank(cm)] = it;
+              npend += __popcll(cm);
+              if (npend >= 64) {
+#if defined(AHK_TIMING) && AHK_TIMING == 1
+                const long long _f0 = (long long)clock64();
+#endif
+                apply_pending(64);
+#if defined(AHK_TIMING) && AHK_TIMING == 1
+                if (tid == 0) { pl_t[1] += (long long)clock64() - _f0; pl_t[5]++; }
+#endif
+                unsigned int mv = 0u;
+                if (lane < npend - 64) mv = pend[64 + lane];
+                if (lane < npend - 64) pend[lane] = mv;
+                npend -= 64;
+              }
+            }
+          };
+          auto fetch = [&](const int i) -> unsigned int { return i < M ? (i < cap ? items_lds[i] : items_glb[i - cap]) : 0u; };
+          unsigned int q[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) q[u] = fetch(tid + u * kBlock);
+          for (int i0 = 0; i0 < M; i0 += 4 * kBlock) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int ib = i0 + u * kBlock;
+              if (ib < M) {  // uniform
+                const unsigned int it = q[u];
+                q[u] = fetch(ib + tid + 4 * kBlock);
+                classify(it, ib + tid < M);
+              }
+            }
+          }
+#if defined(AHK_TIMING) && AHK_TIMING == 1
+          const long long _f1 = (long long)clock64();
+          if (tid == 0) pl_t[0] += _f1 - tlast;
+#endif
+          if (npend > 0) apply_pending(npend);
+          npend = 0;
+#if defined(AHK_TIMING) && AHK_TIMING == 1
+          const long long _f2 = (long long)clock64();
+          if (tid == 0) pl_t[2] += _f2 - _f1;
+#endif
+          __syncthreads();  // hl and slow complete; (the heavy pass re-uses the words of the per-wave lists)
+#if defined(AHK_TIMING) && AHK_TIMING == 1
+          if (tid == 0) { pl_t[3] += (long long)clock64() - _f2; pl_t[6]++; tlast = (long long)clock64(); }
+#endif
+          nh = __builtin_amdgcn_readfirstlane(s_nh);
+          nslow = __builtin_amdgcn_readfirstlane(s_nslow);
         }
+        {
+          // pass B: segment 0 = the item list or the slow list, segment 1 = hl when one lane per edge is the better deal
+          const int cnt0 = classified ? nslow : M;
+          const int cnt1 = (classified && nh > kHeavyMaxItems) ? nh : 0;
+          if (cnt1 > 0) nh = 0;
+          auto fetchB = [&](const int i) -> unsigned int {
+            if (i >= cnt0) return hl[i - cnt0];
+            if (classified) return slow_end[-1 - i];
+            return i < cap ? items_lds[i] : items_glb[i - cap];
+          };
+          unsigned int it_nx = 0u;
+          if (tid < cnt0 + cnt1) it_nx = fetchB(tid);
+          for (int i = tid; i < cnt0 + cnt1; i += kBlock) {
+            const unsigned int it = it_nx;
+            if (i + kBlock < cnt0 + cnt1) it_nx = fetchB(i + kBlock);
+            plain_item(it, (int)(it >> 28), (int)((it >> 24) & 7u));
+          }
+        }
+#if defined(AHK_TIMING) && AHK_TIMING == 1
+        __syncthreads();
+        {
+          // plain-loop cycles by shape: one side a single read and the other side's rows walk no second list / a second list / neither side single
+          const int bigF = nA == 1 ? nFa : nFb;
+          const int cat = (nA == 1 || nB == 1) ? (merge ? (bigF == 0 ? 1 : 2) : 0) : 3;
+          if (tid == 0) {
+            const long long _t = (long long)clock64();
+            pcat_c[cat] += _t - tlast; pcat_n[cat]++; pcat_m[cat] += M; pcat_f[cat] += bigF;
+          }
+        }
+        AHK_T(9);
+#endif
 #if AHK_HEAVY == 1
         // Heavy edges in chunks: the member lists are cut into chunks of kHeavyChunk that are
         // dealt out over all 256 lanes (consecutive lanes = consecutive edges of a row, same
@@ -1368,25 +1593,35 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
               if (dp != 0) atomicAdd(&hacc[2 * hh + 1], (unsigned long long)dp);
             }
             __syncthreads();
-            for (int hh = tid; hh < nr; hh += kBlock) {
-              const long long df = (long long)hacc[2 * hh], dp = (long long)hacc[2 * hh + 1];
-              if (df == 0 && dp == 0) continue;
-              const unsigned int it = hl[r0 + hh];
-              const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
-              const unsigned ici = ic_index(x, b, n);
-              IcPair ic = IC_AT(ici);
-              ic.f += df;
-              ic.p += dp;
-              IC_AT(ici) = ic;
-              IC_AT(ic_index(b, x, n)) = ic;
+            for (int hh0 = 0; hh0 < nr; hh0 += kBlock) {
+              const int hh = hh0 + tid;
+              long long df = 0, dp = 0;
+              if (hh < nr) {
+                df = (long long)hacc[2 * hh];
+                dp = (long long)hacc[2 * hh + 1];
+              }
+              const bool act = df != 0 || dp != 0;
+              int x = 0;
+              unsigned long long c1 = 0ull, c2 = 0ull;
+              if (act) {
+                const unsigned int it = hl[r0 + hh];
+                x = (int)((it >> 12) & 0xfffu);
+                const int b = (int)(it & 0xfffu);
+                const unsigned ici = ic_index(x, b, n);
+                IcPair ic = IC_AT(ici);
+                ic.f += df;
+                ic.p += dp;
+                IC_AT(ici) = ic;
+                IC_AT(ic_index(b, x, n)) = ic;
 #ifdef AHK_TIMING
-              atomicAdd(&s_chg, 1);
+                atomicAdd(&s_chg, 1);
 #endif
-              const unsigned long long c1 = mkkey(ic.f, x, b), c2 = mkkey(ic.p, x, b);
-              fold_key(&bestF[x], c1);
-              fold_key(&bestP[x], c2);
-              fold_key(&bestF[b], c1);
-              fold_key(&bestP[b], c2);
+                c1 = mkkey(ic.f, x, b);
+                c2 = mkkey(ic.p, x, b);
+                fold_key(&bestF[b], c1);
+                fold_key(&bestP[b], c2);
+              }
+              fold_rows_grouped(act, x, c1, c2, bestF, bestP, lane);  // (the heavy edges of a row sit side by side)
             }
             __syncthreads();
           }
@@ -1514,7 +1749,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           }
         }
         if (tid < 4) s_cnt[tid] = 0;
-        if (tid == 0) { s_items = 0; s_nh = 0; }
+        if (tid == 0) { s_items = 0; s_nh = 0; s_nslow = 0; }
         AHK_T(6);  // (diagnostic build: weight rewrites vs rescans)
         // rows whose maximum died: exact rescan now (they would tie the next argmax anyway)
         rescan_list(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
@@ -1538,17 +1773,32 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
 #endif
       if (tid == 0) s_nd = 0;  // next append is behind the P1 reduction barrier
       AHK_T(4);
+      AHK_F(9);
 #ifdef AHK_TIMING
       heavy_it = false;
 #endif
     }
     __syncthreads();
+#ifdef AHK_FTRACE
+    if (tid == 0 && ft_first) {
+      printf("ftrace chain %d n=%d fast=%lld other=%lld | per wave: scan reduce barrier decide | rt1 rt2+update reduce barrier commit | general\n", c, n, ft_nfast, ft_nother);
+      for (int q = 0; q < 4; q++)
+        printf("ftrace wave %d: %llu %llu %llu %llu | %llu %llu %llu %llu %llu | %llu\n", q, s_ft[q][0], s_ft[q][1], s_ft[q][2], s_ft[q][3], s_ft[q][4], s_ft[q][5], s_ft[q][6],
+               s_ft[q][7], s_ft[q][8], s_ft[q][9]);
+    }
+    ft_first = false;
+    __syncthreads();
+#endif
 #ifdef AHK_TIMING
     if (tid == 0 && blockIdx.x == 0)
       printf("chain %d n=%d iters=%lld retries=%lld rescans=%lld sumT=%lld sumM=%lld sumW=%lld | cycles P1=%lld resc=%lld P2=%lld P3a=%lld (loadwait=%lld proc=%lld) P3b=%lld P4=%lld | P3b: decode=%lld tri=%lld fold=%lld\n", c, n, iters,
              nretry, nresc, sumT, sumM, (long long)s_chg, tacc[0], tacc[1], tacc[2], tacc[5], tacc[6], tacc[7], tacc[3], tacc[4], tacc[8], tacc[9], tacc[10]);
     if (tid == 0 && blockIdx.x == 0) {
       printf("merges=%lld sum_nd=%lld fast=%lld fast_cycles=%lld\n", nmerge, sumnd, nfast, tacc[11]);
+      printf("plain loop wave 0: passA trips+flushes=%lld (flushes %lld, n=%lld) tail flush=%lld barrier=%lld passA count=%lld\n", pl_t[0], pl_t[1], pl_t[5], pl_t[2], pl_t[3], pl_t[6]);
+      for (int q = 0; q < 4; q++)
+        printf("plain loop cat %d (0 sep single-sided, 1 merge single-sided no F walk, 2 merge single-sided F walk, 3 other): iters=%lld cycles=%lld items=%lld sumF=%lld\n", q, pcat_n[q],
+               pcat_c[q], pcat_m[q], pcat_f[q]);
       printf("heavy iters=%lld | Mcycles P1=%lld P2=%lld P3a=%lld (P4: rewrite=%lld rescan=%lld) P3b=%lld P4wait=%lld | P3b: decode=%lld tri=%lld fold=%lld\n", nheavy, tacc2[0] / 1000000,
              tacc2[2] / 1000000, tacc2[5] / 1000000, tacc2[6] / 1000000, tacc2[7] / 1000000, tacc2[3] / 1000000, tacc2[4] / 1000000, tacc2[8] / 1000000, tacc2[9] / 1000000, tacc2[10] / 1000000);
       for (int b = 0; b < 8; b++)
@@ -1969,6 +2219,7 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4;  // multiw (padded to 8 bytes)
   b += 2 * 4 * 32 * 8;                                   // rmask, rolenz
   b += (size_t)l.nmax;                     // role
+  b += (size_t)l.nmax * 4;                 // wrow
   {  // the threading DP re-uses the region: tuple-code map (u16) + one marginal table (u64 + u32)
     size_t codes = 1, marg = 1;
     for (int i = 0; i < l.ploidy; i++) { marg = codes; codes *= (size_t)(2 * l.ploidy); }

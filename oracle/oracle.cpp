@@ -338,6 +338,9 @@ struct ClusterEditing {
     dirty[y] = 1;
   }
 
+#ifdef ORACLE_CE_TRACE
+  int trace_fa = 0, trace_fb = 0;
+#endif
   void merge(int u, int v) {
     std::vector<int> A = members[clique[u]], B = members[clique[v]];
     std::vector<char> inAB(n, 0);
@@ -351,6 +354,10 @@ struct ClusterEditing {
       if (za && !zb) fa.push_back(z);
       if (zb && !za) fb.push_back(z);
     }
+#ifdef ORACLE_CE_TRACE
+    trace_fa = (int)fa.size();
+    trace_fb = (int)fb.size();
+#endif
     for (int x : A)
       for (int y : B) set_pair(x, y, W_PERM);
     for (int z : fa)
@@ -425,6 +432,9 @@ struct ClusterEditing {
 #endif
       if (vf >= vp) merge(fu, fv);
       else forbid(pu, pv);
+#ifdef ORACLE_CE_TRACE
+      if (getenv("ORACLE_CE_TRACE_F") && vf >= vp) fprintf(stderr, "MERGE_F %d %d\n", trace_fa, trace_fb);
+#endif
     }
     // clusters ordered by smallest member, members ascending
     std::vector<int> cl(n, -1);
