@@ -14,7 +14,9 @@
 #include <cstring>
 #include <new>
 #include <numeric>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -41,6 +43,29 @@ struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
 };
+
+// Host loops over the batch (validation, per-chain metadata, the name CSR) walk every
+// alignment node once: ~2*10^8 entries at config 3.  fn(lo, hi) runs on contiguous index
+// ranges of [0, n) on up to 16 host threads; ranges are independent by construction.
+template <class F>
+void parallel_ranges(long long n, long long grain, F fn) {
+  unsigned T = std::thread::hardware_concurrency();
+  if (T == 0) T = 1;
+  if (T > 16) T = 16;
+  const long long want = grain > 0 ? (n + grain - 1) / grain : 1;
+  if ((long long)T > want) T = (unsigned)(want < 1 ? 1 : want);
+  if (T <= 1) {
+    fn(0LL, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  th.reserve(T);
+  for (unsigned t = 0; t < T; t++) {
+    const long long lo = n * t / T, hi = n * (t + 1) / T;
+    th.emplace_back([=] { fn(lo, hi); });
+  }
+  for (auto& x : th) x.join();
+}
 
 }  // namespace
 
@@ -153,39 +178,50 @@ int ahk::validate_batch(const ahsoka_chain_batch* in) {
         in->node_off[c + 1] < in->node_off[c])
       return AHSOKA_E_ARG;
   const long long SB = in->bubble_off[C], SR = in->read_off[C];
-  for (long long g = 0; g < SB; g++)
-    if (in->allele_off[g + 1] < in->allele_off[g]) return AHSOKA_E_ARG;
+  std::atomic<int> bad{0};
+  parallel_ranges(SB, 1 << 16, [&](long long lo, long long hi) {
+    for (long long g = lo; g < hi; g++)
+      if (in->allele_off[g + 1] < in->allele_off[g]) { bad = 1; return; }
+  });
+  if (bad) return AHSOKA_E_ARG;
   const long long SA = in->allele_off[SB];
-  for (long long a = 0; a < SA; a++)
-    if (in->apath_off[a + 1] < in->apath_off[a]) return AHSOKA_E_ARG;
-  for (long long r = 0; r < SR; r++)
-    if (in->rnode_off[r + 1] < in->rnode_off[r]) return AHSOKA_E_ARG;
+  parallel_ranges(SA, 1 << 16, [&](long long lo, long long hi) {
+    for (long long a = lo; a < hi; a++)
+      if (in->apath_off[a + 1] < in->apath_off[a]) { bad = 1; return; }
+  });
+  parallel_ranges(SR, 1 << 16, [&](long long lo, long long hi) {
+    for (long long r = lo; r < hi; r++)
+      if (in->rnode_off[r + 1] < in->rnode_off[r]) { bad = 1; return; }
+  });
+  if (bad) return AHSOKA_E_ARG;
   if (in->apath_off[SA] > 0 && !in->apath_node) return AHSOKA_E_ARG;
   if (SR > 0 && (!in->read_mapq || !in->read_name)) return AHSOKA_E_ARG;
   if (in->rnode_off[SR] > 0 && !in->rnode) return AHSOKA_E_ARG;
   // node indices must be chain-local and in range: the kernels index LDS with them
-  for (int c = 0; c < C; c++) {
-    const long long N = in->node_off[c + 1] - in->node_off[c];
-    for (long long g = in->bubble_off[c]; g < in->bubble_off[c + 1]; g++)
-      for (long long a = in->allele_off[g]; a < in->allele_off[g + 1]; a++)
-        for (long long e = in->apath_off[a]; e < in->apath_off[a + 1]; e++)
-          if (in->apath_node[e] < 0 || in->apath_node[e] >= N) return AHSOKA_E_ARG;
-    for (long long r = in->read_off[c]; r < in->read_off[c + 1]; r++) {
-      for (long long e = in->rnode_off[r]; e < in->rnode_off[r + 1]; e++)
-        if (in->rnode[e] < -1 || in->rnode[e] >= N) return AHSOKA_E_ARG;
-      if (in->read_name[r] < 0 || in->read_name[r] >= in->read_off[c + 1] - in->read_off[c]) return AHSOKA_E_ARG;
-    }
-    if (in->s1_order) {  // must be a permutation of the chain's bubble ids
-      const long long b0 = in->bubble_off[c], B = in->bubble_off[c + 1] - b0;
-      std::vector<unsigned char> seen((size_t)B, 0);
-      for (long long k = 0; k < B; k++) {
-        const int v = in->s1_order[b0 + k];
-        if (v < 0 || v >= B || seen[(size_t)v]) return AHSOKA_E_ARG;
-        seen[(size_t)v] = 1;
+  parallel_ranges(C, 8, [&](long long c0, long long c1) {
+    for (long long c = c0; c < c1; c++) {
+      const long long N = in->node_off[c + 1] - in->node_off[c];
+      for (long long g = in->bubble_off[c]; g < in->bubble_off[c + 1]; g++)
+        for (long long a = in->allele_off[g]; a < in->allele_off[g + 1]; a++)
+          for (long long e = in->apath_off[a]; e < in->apath_off[a + 1]; e++)
+            if (in->apath_node[e] < 0 || in->apath_node[e] >= N) { bad = 1; return; }
+      for (long long r = in->read_off[c]; r < in->read_off[c + 1]; r++) {
+        for (long long e = in->rnode_off[r]; e < in->rnode_off[r + 1]; e++)
+          if (in->rnode[e] < -1 || in->rnode[e] >= N) { bad = 1; return; }
+        if (in->read_name[r] < 0 || in->read_name[r] >= in->read_off[c + 1] - in->read_off[c]) { bad = 1; return; }
+      }
+      if (in->s1_order) {  // must be a permutation of the chain's bubble ids
+        const long long b0 = in->bubble_off[c], B = in->bubble_off[c + 1] - b0;
+        std::vector<unsigned char> seen((size_t)B, 0);
+        for (long long k = 0; k < B; k++) {
+          const int v = in->s1_order[b0 + k];
+          if (v < 0 || v >= B || seen[(size_t)v]) { bad = 1; return; }
+          seen[(size_t)v] = 1;
+        }
       }
     }
-  }
-  return AHSOKA_OK;
+  });
+  return bad ? AHSOKA_E_ARG : AHSOKA_OK;
 }
 
 extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_phase_params* prm,
@@ -207,7 +243,9 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   const int C = h->C = in->n_chains;
   std::memset(&h->db, 0, sizeof(h->db));
   int rc = AHSOKA_OK;
+  std::thread copier;
   auto fail = [&](int code) {
+    if (copier.joinable()) copier.join();
     ahsoka_batch_free(h);
     return code;
   };
@@ -216,66 +254,123 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   h->n_cu = prop.multiProcessorCount;
   h->lds_per_block = (size_t)prop.sharedMemPerBlock;
 
+  // ---- inputs to HBM: the caller's arrays go as they are, copied by a second host thread while
+  // this one derives the per-chain metadata (0.8 GB at config 3: the copy and the host loops take
+  // about as long as each other)
+  DeviceBatch& db = h->db;
+  const long long SB = in->bubble_off[C], SA = in->allele_off[SB], SP = in->apath_off[SA], SR = in->read_off[C],
+                  SL = in->rnode_off[SR];
+  struct RawCopy {
+    void* dst;
+    const void* src;
+    size_t bytes;
+  };
+  std::vector<RawCopy> raw;
+  auto stage = [&](auto** out, const auto* src, size_t count) -> int {
+    typename std::remove_const<typename std::remove_pointer<decltype(src)>::type>::type* p = nullptr;
+    if (int e = h->dalloc(&p, count)) return e;
+    raw.push_back(RawCopy{p, src, count * sizeof(*p)});
+    *out = p;
+    return AHSOKA_OK;
+  };
+  if ((rc = stage(&db.allele_off, (const long long*)in->allele_off, (size_t)SB + 1))) return fail(rc);
+  if ((rc = stage(&db.apath_off, (const long long*)in->apath_off, (size_t)SA + 1))) return fail(rc);
+  if ((rc = stage(&db.apath_node, (const int*)in->apath_node, (size_t)SP))) return fail(rc);
+  if (in->genotype) {
+    if ((rc = stage(&db.genotype, (const int*)in->genotype, (size_t)SA))) return fail(rc);
+  } else {
+    db.genotype = nullptr;
+  }
+  if ((rc = stage(&db.rnode_off, (const long long*)in->rnode_off, (size_t)SR + 1))) return fail(rc);
+  if ((rc = stage(&db.rnode, (const int*)in->rnode, (size_t)SL))) return fail(rc);
+  if ((rc = stage(&db.read_mapq, (const int*)in->read_mapq, (size_t)SR))) return fail(rc);
+  if (in->read_flags)
+    if ((rc = stage(&db.read_flags, (const unsigned char*)in->read_flags, (size_t)SR))) return fail(rc);
+  if (in->s1_order)
+    if ((rc = stage(&db.s1_order, (const int*)in->s1_order, (size_t)SB))) return fail(rc);
+  std::atomic<int> copy_rc{AHSOKA_OK};
+  copier = std::thread([&raw, &copy_rc, dev = prm->device] {
+    if (hipSetDevice(dev) != hipSuccess) {
+      copy_rc = AHSOKA_E_NODEVICE;
+      return;
+    }
+    for (const RawCopy& r : raw)
+      if (r.bytes && hipMemcpy(r.dst, r.src, r.bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        copy_rc = AHSOKA_E_HIP;
+        return;
+      }
+  });
+
   // ---- per-chain metadata, name CSR, limits --------------------------------
+  // Three steps: (1) per chain, in parallel: sizes, limits, repeated-node flags, which readset
+  // kernel fits; (2) serial prefix sums of the per-chain array offsets; (3) per chain, in
+  // parallel: the name CSR (alignments of one read name side by side).
   h->meta.resize(C);
-  std::vector<long long> name_off;
   std::vector<int> name_aln((size_t)in->read_off[C]);
   std::vector<unsigned char> apath_dup((size_t)in->allele_off[in->bubble_off[C]] + 1, 0);
+  std::vector<ReadsetLds2> need2v((size_t)C);
+  std::vector<int> maxAv((size_t)C, 2);
   int maxA = 2, maxG = 1, maxB = 1, maxN = 1;
   long long vm = 0, fr = 0, cov = 0, dump = 0;
   std::vector<int> fit_list, big_list;
   h->rl2 = ReadsetLds2{1, 1, 1, 1, 1, 1};
   h->maxB = 1;
+  const size_t lds_per_block = h->lds_per_block;
+  parallel_ranges(C, 8, [&](long long c0, long long c1) {
+    for (long long c = c0; c < c1; c++) {
+      ChainMeta& m = h->meta[(size_t)c];
+      std::memset(&m, 0, sizeof(m));
+      m.b0 = in->bubble_off[c];
+      m.r0 = in->read_off[c];
+      m.n0 = in->node_off[c];
+      m.B = (int)(in->bubble_off[c + 1] - m.b0);
+      m.R = (int)(in->read_off[c + 1] - m.r0);
+      m.N = (int)(in->node_off[c + 1] - m.n0);
+      int G = 0;
+      for (int r = 0; r < m.R; r++) G = std::max(G, in->read_name[m.r0 + r] + 1);
+      m.G = G;
+      m.Wb = (m.B + 63) / 64;
+      bool unsupported = m.B > kMaxBubbles || m.N > kMaxNodes || G > kMaxNames || m.R > 131071;
+      // a chain whose k_readset working set does not fit this device's LDS is reported
+      // per chain, like the compiled-in limits, instead of failing the whole batch
+      if (!unsupported && readset_lds_bytes(ReadsetLds{(m.N + 63) / 64, std::max(G, 1), std::max(m.B, 1)}) > lds_per_block)
+        unsupported = true;
+      int mA = 2;
+      for (long long g = m.b0; g < m.b0 + m.B; g++) {
+        const int na = (int)(in->allele_off[g + 1] - in->allele_off[g]);
+        if (na > kMaxAlleles) unsupported = true;
+        mA = std::max(mA, std::min(na, kMaxAlleles));
+        for (long long a = in->allele_off[g]; a < in->allele_off[g + 1]; a++) {
+          // std::includes is a multiset test (quirk Q5); the bit test equals it only
+          // for paths without repeated nodes: flag the others for the counting path
+          const long long p0 = in->apath_off[a], p1 = in->apath_off[a + 1];
+          for (long long e = p0; e < p1 && !apath_dup[(size_t)a]; e++)
+            for (long long e2 = e + 1; e2 < p1; e2++)
+              if (in->apath_node[e] == in->apath_node[e2]) { apath_dup[(size_t)a] = 1; break; }
+        }
+      }
+      maxAv[(size_t)c] = mA;
+      // chains whose alignment bitsets fit the LDS as a whole take k_readset_lds: no R x B match
+      // matrices in HBM unless the stage dumps are wanted
+      const long long SAc = in->allele_off[m.b0 + m.B] - in->allele_off[m.b0];
+      const ReadsetLds2 need2{(int)std::min<long long>((long long)((m.N + 63) / 64) * m.R, 1 << 28),
+                              (int)std::min<long long>((long long)((m.N + 63) / 64) * SAc, 1 << 28),
+                              m.R, std::max(G, 1), std::max(m.B, 1), (int)std::min<long long>(SAc, 65535)};
+      need2v[(size_t)c] = need2;
+      const bool fit = unsupported || m.B <= 1 ||
+                       (SAc < 65535 && readset_lds2_bytes(need2) <= std::min<size_t>(lds_per_block, kReadsetFitBytes));
+      m.flags = (unsupported ? 1 : 0) | (fit ? 2 : 0);
+    }
+  });
+  long long names_total = 0;
   for (int c = 0; c < C; c++) {
     ChainMeta& m = h->meta[c];
-    std::memset(&m, 0, sizeof(m));
-    m.b0 = in->bubble_off[c];
-    m.r0 = in->read_off[c];
-    m.n0 = in->node_off[c];
-    m.B = (int)(in->bubble_off[c + 1] - m.b0);
-    m.R = (int)(in->read_off[c + 1] - m.r0);
-    m.N = (int)(in->node_off[c + 1] - m.n0);
-    int G = 0;
-    for (int r = 0; r < m.R; r++) G = std::max(G, in->read_name[m.r0 + r] + 1);
-    m.G = G;
-    m.Wb = (m.B + 63) / 64;
-    m.name0 = (long long)name_off.size();
-    // counting sort of the chain's alignments by name id (stable: ascending alignment index)
-    std::vector<long long> cnt((size_t)G + 1, 0);
-    for (int r = 0; r < m.R; r++) cnt[in->read_name[m.r0 + r] + 1]++;
-    for (int g = 0; g < G; g++) cnt[g + 1] += cnt[g];
-    for (int g = 0; g <= G; g++) name_off.push_back(cnt[g]);
-    {
-      std::vector<long long> cur(cnt.begin(), cnt.end() - 1);
-      for (int r = 0; r < m.R; r++) name_aln[(size_t)m.r0 + cur[in->read_name[m.r0 + r]]++] = r;
-    }
-    bool unsupported = m.B > kMaxBubbles || m.N > kMaxNodes || G > kMaxNames || m.R > 131071;
-    // a chain whose k_readset working set does not fit this device's LDS is reported
-    // per chain, like the compiled-in limits, instead of failing the whole batch
-    if (!unsupported && readset_lds_bytes(ReadsetLds{(m.N + 63) / 64, std::max(G, 1), std::max(m.B, 1)}) > h->lds_per_block)
-      unsupported = true;
-    for (long long g = m.b0; g < m.b0 + m.B; g++) {
-      const int na = (int)(in->allele_off[g + 1] - in->allele_off[g]);
-      if (na > kMaxAlleles) unsupported = true;
-      maxA = std::max(maxA, std::min(na, kMaxAlleles));
-      for (long long a = in->allele_off[g]; a < in->allele_off[g + 1]; a++) {
-        // std::includes is a multiset test (quirk Q5); the bit test equals it only
-        // for paths without repeated nodes: flag the others for the counting path
-        const long long p0 = in->apath_off[a], p1 = in->apath_off[a + 1];
-        for (long long e = p0; e < p1 && !apath_dup[(size_t)a]; e++)
-          for (long long e2 = e + 1; e2 < p1; e2++)
-            if (in->apath_node[e] == in->apath_node[e2]) { apath_dup[(size_t)a] = 1; break; }
-      }
-    }
-    // chains whose alignment bitsets fit the LDS as a whole take k_readset_lds: no R x B match
-    // matrices in HBM unless the stage dumps are wanted
-    const long long SAc = in->allele_off[m.b0 + m.B] - in->allele_off[m.b0];
-    const ReadsetLds2 need2{(int)std::min<long long>((long long)((m.N + 63) / 64) * m.R, 1 << 28),
-                            (int)std::min<long long>((long long)((m.N + 63) / 64) * SAc, 1 << 28),
-                            m.R, std::max(G, 1), std::max(m.B, 1), (int)std::min<long long>(SAc, 65535)};
-    const bool fit = unsupported || m.B <= 1 ||
-                     (SAc < 65535 && readset_lds2_bytes(need2) <= std::min<size_t>(h->lds_per_block, kReadsetFitBytes));
-    m.flags = (unsupported ? 1 : 0) | (fit ? 2 : 0);
+    const int G = m.G;
+    const bool unsupported = (m.flags & 1) != 0, fit = (m.flags & 2) != 0;
+    const ReadsetLds2& need2 = need2v[(size_t)c];
+    maxA = std::max(maxA, maxAv[(size_t)c]);
+    m.name0 = names_total;
+    names_total += (long long)G + 1;
     m.vmat0 = (fit && !prm->want_stages) ? -1 : vm;
     m.fr0 = fr;
     m.cov0 = cov;
@@ -311,6 +406,21 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
       }
     }
   }
+  std::vector<long long> name_off((size_t)names_total);
+  parallel_ranges(C, 8, [&](long long c0, long long c1) {
+    std::vector<long long> cur;
+    for (long long c = c0; c < c1; c++) {
+      const ChainMeta& m = h->meta[(size_t)c];
+      const int G = m.G;
+      // counting sort of the chain's alignments by name id (stable: ascending alignment index)
+      long long* cnt = name_off.data() + m.name0;  // [G+1]
+      for (int g = 0; g <= G; g++) cnt[g] = 0;
+      for (int r = 0; r < m.R; r++) cnt[in->read_name[m.r0 + r] + 1]++;
+      for (int g = 0; g < G; g++) cnt[g + 1] += cnt[g];
+      cur.assign(cnt, cnt + G);
+      for (int r = 0; r < m.R; r++) name_aln[(size_t)m.r0 + cur[in->read_name[m.r0 + r]]++] = r;
+    }
+  });
   h->sumB = in->bubble_off[C];
   h->sumR = in->read_off[C];
   h->sumG = fr;
@@ -320,32 +430,16 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   int planes = 1;
   while ((1 << planes) < maxA) planes++;
 
-  // ---- inputs to HBM ---------------------------------------------------------
-  DeviceBatch& db = h->db;
-  const long long SB = in->bubble_off[C], SA = in->allele_off[SB], SP = in->apath_off[SA], SR = in->read_off[C],
-                  SL = in->rnode_off[SR];
-  if ((rc = h->dupload(&db.allele_off, (const long long*)in->allele_off, (size_t)SB + 1))) return fail(rc);
-  if ((rc = h->dupload(&db.apath_off, (const long long*)in->apath_off, (size_t)SA + 1))) return fail(rc);
-  if ((rc = h->dupload(&db.apath_node, (const int*)in->apath_node, (size_t)SP))) return fail(rc);
+  // ---- derived inputs ---------------------------------------------------------------
   if ((rc = h->dupload(&db.apath_dup, (const unsigned char*)apath_dup.data(), (size_t)SA + 1))) return fail(rc);
-  if (in->genotype) {
-    if ((rc = h->dupload(&db.genotype, (const int*)in->genotype, (size_t)SA))) return fail(rc);
-  } else {
-    db.genotype = nullptr;
-  }
-  if ((rc = h->dupload(&db.rnode_off, (const long long*)in->rnode_off, (size_t)SR + 1))) return fail(rc);
-  if ((rc = h->dupload(&db.rnode, (const int*)in->rnode, (size_t)SL))) return fail(rc);
-  if ((rc = h->dupload(&db.read_mapq, (const int*)in->read_mapq, (size_t)SR))) return fail(rc);
-  if (in->read_flags) {
-    if ((rc = h->dupload(&db.read_flags, (const unsigned char*)in->read_flags, (size_t)SR))) return fail(rc);
-  } else {  // documented fallback: the guard of :245 on the truncated identity
+  if (!in->read_flags) {  // documented fallback: the guard of :245 on the truncated identity
     std::vector<unsigned char> fl((size_t)SR);
-    for (long long r = 0; r < SR; r++) fl[(size_t)r] = in->read_mapq[r] > 90 ? 1 : 0;
+    parallel_ranges(SR, 1 << 18, [&](long long lo, long long hi) {
+      for (long long r = lo; r < hi; r++) fl[(size_t)r] = in->read_mapq[r] > 90 ? 1 : 0;
+    });
     if ((rc = h->dupload(&db.read_flags, (const unsigned char*)fl.data(), (size_t)SR))) return fail(rc);
   }
-  if (in->s1_order) {
-    if ((rc = h->dupload(&db.s1_order, (const int*)in->s1_order, (size_t)SB))) return fail(rc);
-  } else {  // the order the reference's own map construction gives (host_batch.h)
+  if (!in->s1_order) {  // the order the reference's own map construction gives (host_batch.h)
     std::vector<int32_t> ord;
     ord.reserve((size_t)SB);
     std::vector<std::vector<int32_t>> memo;  // by B: chains of equal size share the order
@@ -420,6 +514,8 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   if (hipStreamCreate(&h->stream) != hipSuccess) return fail(AHSOKA_E_HIP);
   for (int i = 0; i < 3; i++)
     if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(AHSOKA_E_HIP);
+  copier.join();
+  if (copy_rc != AHSOKA_OK) return fail(copy_rc);
   *handle = h;
   return AHSOKA_OK;
 }
