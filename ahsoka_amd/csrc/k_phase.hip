@@ -1029,7 +1029,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       // other side's rows y has the one triangle (y,rs,b), whose two other edges W[rs][y] and
       // W[rs][b] both sit in row rs.  That row goes to LDS now; P3b then prices those edges
       // (thousands per iteration, 4 % of them change) without touching HBM.
-      const int rs = __builtin_amdgcn_readfirstlane(!((multiw[eu >> 5] >> (eu & 31)) & 1u) ? eu : (!((multiw[ev >> 5] >> (ev & 31)) & 1u) ? ev : -1));
+      const int rs = !lds.stage_row ? -1
+                                    : __builtin_amdgcn_readfirstlane(!((multiw[eu >> 5] >> (eu & 31)) & 1u) ? eu : (!((multiw[ev >> 5] >> (ev & 31)) & 1u) ? ev : -1));
       if (rs >= 0)
         for (int z = tid; z < n; z += kBlock) wrow[z] = WM_AT((unsigned)(rs * n + z));
 
@@ -2219,7 +2220,7 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4;  // multiw (padded to 8 bytes)
   b += 2 * 4 * 32 * 8;                                   // rmask, rolenz
   b += (size_t)l.nmax;                     // role
-  b += (size_t)l.nmax * 4;                 // wrow
+  if (l.stage_row) b += (size_t)l.nmax * 4;  // wrow
   {  // the threading DP re-uses the region: tuple-code map (u16) + one marginal table (u64 + u32)
     size_t codes = 1, marg = 1;
     for (int i = 0; i < l.ploidy; i++) { marg = codes; codes *= (size_t)(2 * l.ploidy); }

@@ -556,7 +556,7 @@ static int build_classes(ahsoka_device_batch* h) {
   // largest readset whose per-read LDS arrays fit a workgroup of this device
   int ncap = 64;
   for (int v = 64; v <= ((kMaxReads + 63) & ~63); v += 64) {
-    PhaseLds t{v, 0, h->prm.ploidy};
+    PhaseLds t{v, 0, h->prm.ploidy, 0};
     if (phase_lds_bytes(t) <= h->lds_per_block) ncap = v;
   }
   bool demoted = false;
@@ -604,7 +604,14 @@ static int build_classes(ahsoka_device_batch* h) {
     pc.pl.stop_after = h->stop_after;
     pc.pl.ploidy = h->prm.ploidy;
     for (int c : members[k]) pc.Pmax = std::max(pc.Pmax, h->meta[(size_t)c].B);
-    const int per_cu = std::min(phase_max_blocks_per_cu(pc.pl), per_cu_cap);
+    // the staged weight row of S5 (4 more bytes of LDS per read) only where it does not cost occupancy
+    pc.pl.stage_row = 0;
+    int per_cu = std::min(phase_max_blocks_per_cu(pc.pl), per_cu_cap);
+    {
+      PhaseLds with = pc.pl;
+      with.stage_row = 1;
+      if (phase_lds_bytes(with) <= h->lds_per_block && std::min(phase_max_blocks_per_cu(with), per_cu_cap) >= per_cu) pc.pl = with;
+    }
     pc.slots = std::max(1, std::min(pc.count, h->n_cu * per_cu));
     if (h->prm.max_slots > 0) pc.slots = std::min(pc.slots, h->prm.max_slots);
     h->classes.push_back(pc);

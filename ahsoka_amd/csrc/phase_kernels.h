@@ -121,6 +121,7 @@ struct PhaseLds {
   int nmax;        // capacity of the per-read LDS arrays
   int stop_after;  // diagnostic builds (-DAHK_DIAG) only: 1/2/3 = stop after S4 / S5 init / S5 loop
   int ploidy;      // the threading DP's tables ((2p)^p tuple codes, (2p)^(p-1) marginal minima) share the LDS
+  int stage_row;   // 1: room for the staged weight row (4 B per read) -- set when it does not cost a workgroup per CU
 };
 struct ReadsetLds2 {  // k_readset_lds
   int maxBitWords;   // max over its chains of ceil(N/64) * R: u64 words of all alignment bitsets
