@@ -587,8 +587,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
   unsigned short* listB = listA + nmax;
   unsigned short* listFa = listB + nmax;
   unsigned short* listFb = listFa + nmax;
-  unsigned short* rowbuf = listFb + nmax;                 // [4][nmax] per-wave column buffers
-  unsigned short* dlist = rowbuf + 4 * (size_t)nmax;      // [nmax] rows whose maximum must be rescanned
+  unsigned short* rowbuf = listFb + nmax;                 // [4][nmax] as u16 = the first 2*nmax entries of the candidate-edge list (absent if !lds.items_lds)
+  unsigned short* dlist = rowbuf + (lds.items_lds ? 4 * (size_t)nmax : 0);  // [nmax] rows whose maximum must be rescanned
   unsigned int* multiw = (unsigned int*)(dlist + nmax);   // [nmax/32] bit per read: its clique has > 1 member
   unsigned long long* rmask = (unsigned long long*)(multiw + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][32] role masks per 64-column word
   unsigned long long* rolenz = rmask + 4 * 32;             // [4][32] OR of the members' nz-rows
@@ -760,8 +760,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     for (int u = tid; u < n; u += kBlock) { bestF[u] = 0ull; bestP[u] = 0ull; }
     __syncthreads();
     {
-      unsigned short* nbr = rowbuf + (size_t)wv * nmax;   // all neighbours of a
-      unsigned short* nhi = listA + (size_t)wv * nmax;    // the neighbours b > a (role lists are free here)
+      unsigned short* nbr = listA + (size_t)wv * nmax;   // all neighbours of a, ascending (the role lists are free here)
       for (int a = wv; a < n; a += 4) {
         int deg = 0, dhi = 0;
         for (int w0 = 0; w0 < n; w0 += 64) {
@@ -771,7 +770,6 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
 
           const unsigned long long mh = __ballot(nz && w > a);
           if (nz) nbr[deg + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)w;
-          if (nz && w > a) nhi[dhi + __popcll(mh & ((1ull << lane) - 1ull))] = (unsigned short)w;
           deg += __popcll(mk);
           dhi += __popcll(mh);
           if (lane == 0) {
@@ -783,6 +781,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         // 64 of them are fetched with ONE load (lane = neighbour index) and handed out
         // with v_readlane -- as scalar operands -- instead of 64 uniform loads; padding
         // neighbours read as weight 0 (both terms vanish), so nothing is predicated.
+        const unsigned short* nhi = nbr + (deg - dhi);  // the neighbours b > a: the tail of the ascending list
         for (int i0 = 0; i0 < dhi; i0 += 64) {
           const int i = i0 + lane;
           const bool act = i < dhi;
@@ -1128,7 +1127,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       // rescan in P4; every other row maximum is maintained lazily.
       {
         unsigned int* items_lds = (unsigned int*)rowbuf;
-        const int cap = 2 * nmax;
+        const int cap = lds.items_lds ? 2 * nmax : 0;
         // Lane layout: a wave works on RP = 64/nwp rows at once, lane = (row slot,
         // 64-column word), nwp = nw rounded up to a power of two (>= 8).  With
         // 10 words per row that is 4 rows per wave pass, 16 per workgroup pass.
@@ -1246,7 +1245,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
       // ---- P3b: one lane per candidate edge ---------------------------------------
       {
         const unsigned int* items_lds = (const unsigned int*)rowbuf;
-        const int cap = 2 * nmax;
+        const int cap = lds.items_lds ? 2 * nmax : 0;
         const int M = __builtin_amdgcn_readfirstlane(s_items);
 #ifdef AHK_TIMING
         sumM += M;
@@ -2216,7 +2215,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
 size_t phase_lds_bytes(const PhaseLds& l) {
   size_t b = (size_t)l.nmax * 8 * 2;       // bestF, bestP
   b += (size_t)l.nmax * 2 * 5;             // cl + 4 lists
-  b += (size_t)l.nmax * 2 * 5;             // rowbuf[4], dlist
+  b += (size_t)l.nmax * 2 * (l.items_lds ? 5 : 1);  // rowbuf[4] (the LDS part of the candidate-edge list), dlist
   b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4;  // multiw (padded to 8 bytes)
   b += 2 * 4 * 32 * 8;                                   // rmask, rolenz
   b += (size_t)l.nmax;                     // role

@@ -556,7 +556,7 @@ static int build_classes(ahsoka_device_batch* h) {
   // largest readset whose per-read LDS arrays fit a workgroup of this device
   int ncap = 64;
   for (int v = 64; v <= ((kMaxReads + 63) & ~63); v += 64) {
-    PhaseLds t{v, 0, h->prm.ploidy, 0};
+    PhaseLds t{v, 0, h->prm.ploidy, 0, 0};
     if (phase_lds_bytes(t) <= h->lds_per_block) ncap = v;
   }
   bool demoted = false;
@@ -604,9 +604,23 @@ static int build_classes(ahsoka_device_batch* h) {
     pc.pl.stop_after = h->stop_after;
     pc.pl.ploidy = h->prm.ploidy;
     for (int c : members[k]) pc.Pmax = std::max(pc.Pmax, h->meta[(size_t)c].B);
-    // the staged weight row of S5 (4 more bytes of LDS per read) only where it does not cost occupancy
+    // LDS extras of S5 by occupancy: the LDS part of the candidate-edge list (8 B per read) is
+    // dropped where that buys a workgroup per CU; the staged weight row (4 B per read) is added
+    // where it does not cost one
     pc.pl.stage_row = 0;
+    pc.pl.items_lds = 1;
     int per_cu = std::min(phase_max_blocks_per_cu(pc.pl), per_cu_cap);
+    {
+      PhaseLds lean = pc.pl;
+      lean.items_lds = 0;
+      const int per_cu_lean = std::min(phase_max_blocks_per_cu(lean), per_cu_cap);
+      // (only where there are chains to fill the extra workgroups: a class that is in flight as a
+      // whole is bound by its largest chain, which more co-resident workgroups only slow down)
+      if ((per_cu_lean > per_cu && pc.count > h->n_cu * per_cu) || phase_lds_bytes(pc.pl) > h->lds_per_block) {
+        pc.pl = lean;
+        per_cu = per_cu_lean;
+      }
+    }
     {
       PhaseLds with = pc.pl;
       with.stage_row = 1;

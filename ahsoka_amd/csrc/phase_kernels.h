@@ -122,6 +122,8 @@ struct PhaseLds {
   int stop_after;  // diagnostic builds (-DAHK_DIAG) only: 1/2/3 = stop after S4 / S5 init / S5 loop
   int ploidy;      // the threading DP's tables ((2p)^p tuple codes, (2p)^(p-1) marginal minima) share the LDS
   int stage_row;   // 1: room for the staged weight row (4 B per read) -- set when it does not cost a workgroup per CU
+  int items_lds;   // 1: the first 2*nmax candidate edges of an iteration are listed in LDS (8 B per read), 0: all in HBM
+                   //    -- dropped when that buys a workgroup per CU
 };
 struct ReadsetLds2 {  // k_readset_lds
   int maxBitWords;   // max over its chains of ceil(N/64) * R: u64 words of all alignment bitsets
