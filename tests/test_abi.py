@@ -110,6 +110,36 @@ def test_batch_validation_rejects_out_of_range_nodes():
     assert capi.lib().ahsoka_batch_upload(bad.ptr(), C.byref(prm), C.byref(h)) == capi.E_ARG
 
 
+@pytest.mark.parametrize("defect", ["rnode_last", "apath_node_last", "read_name_mid", "s1_order_dup", "rnode_off_dip"])
+def test_threaded_validation_finds_a_defect_anywhere(defect):
+    """The batch is validated on several host threads, each over a range of chains: a defect in
+    the last range (or in the middle) must come back E_ARG exactly as one in the first."""
+    import numpy as np
+
+    b = capi.synth_batch(n_chains=400, n_bubbles=6, n_reads=40, seed=5)
+    a = {k: (v.copy() if v is not None else None) for k, v in b.arrays().items()}
+    if defect == "rnode_last":
+        a["rnode"][-1] = 1_000_000
+    elif defect == "apath_node_last":
+        a["apath_node"][-1] = -2
+    elif defect == "read_name_mid":
+        a["read_name"][len(a["read_name"]) // 2] = 10_000
+    elif defect == "s1_order_dup":
+        if a.get("s1_order") is None:
+            pytest.skip("generator does not emit s1_order")
+        a["s1_order"][-1] = a["s1_order"][-2]
+    elif defect == "rnode_off_dip":
+        a["rnode_off"][len(a["rnode_off"]) // 2] -= 1_000
+    bad = capi.ChainBatch(arrays={k: v for k, v in a.items() if v is not None})
+    h = C.c_void_p()
+    prm = capi.default_params()
+    assert capi.lib().ahsoka_batch_upload(bad.ptr(), C.byref(prm), C.byref(h)) == capi.E_ARG
+    # and the untouched batch passes validation (what comes next needs a device)
+    assert capi.lib().ahsoka_batch_upload(b.ptr(), C.byref(prm), C.byref(h)) in (0, capi.E_NODEVICE)
+    if h.value:
+        capi.lib().ahsoka_batch_free(h)
+
+
 def test_synth_is_deterministic_and_shardable():
     import numpy as np
 
