@@ -418,7 +418,7 @@ __device__ __forceinline__ void pair_overlap(const ChainCtx& cx, int i, int j, i
 // flat_* instructions, which count on lgkmcnt as well -- every LDS wait then
 // also waits for all outstanding HBM traffic (measured: whole-kernel slowdown).
 #ifndef AHK_FAST_BATCH
-#define AHK_FAST_BATCH 4
+#define AHK_FAST_BATCH 5
 #endif
 constexpr int kFastBatch = AHK_FAST_BATCH;  // live words of a row a wave of the fast path loads together
 #ifndef AHK_P3B_FULL
