@@ -626,6 +626,10 @@ static int build_classes(ahsoka_device_batch* h) {
       with.stage_row = 1;
       if (phase_lds_bytes(with) <= h->lds_per_block && std::min(phase_max_blocks_per_cu(with), per_cu_cap) >= per_cu) pc.pl = with;
     }
+#ifdef AHK_DIAG
+    std::fprintf(stderr, "ahsoka: class nmax=%d chains=%d workgroups/CU=%d lds=%zu B items_lds=%d stage_row=%d\n", pc.nmax, pc.count, per_cu,
+                 phase_lds_bytes(pc.pl), pc.pl.items_lds, pc.pl.stage_row);
+#endif
     pc.slots = std::max(1, std::min(pc.count, h->n_cu * per_cu));
     if (h->prm.max_slots > 0) pc.slots = std::min(pc.slots, h->prm.max_slots);
     h->classes.push_back(pc);
