@@ -1,5 +1,7 @@
 #!/bin/bash
 # vector-memory path counters of k_phase: is the per-CU address/L1 pipeline the limit?
+# WARNING (rounds 1 and 2): the third counter set (TCP_*) makes rocprofv3 hang without output on this
+# pool until the job is killed for silence -- run at most the first two sets, under `timeout -k 10 300`.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 CH=${1:-1280}
 i=0
