@@ -2,7 +2,7 @@
 """Extended differential soak (not collected by pytest): GPU vs CPU oracle, all stages, on many
 more random irregular batches and synthetic shapes than the regular suite runs.
 
-    python tests/soak_gpu.py [n_random] [n_shapes]
+    python tests/soak_gpu.py [n_random] [n_shapes] [seed_offset]
 
 Prints one line per 10 cases and a final verdict; exits non-zero on the first mismatch."""
 import os
@@ -22,10 +22,11 @@ from test_gpu_parity import _compare  # noqa: E402
 def main():
     n_random = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     n_shapes = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-    rng = np.random.default_rng(20261004)
+    off = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # a different region of the random space per run
+    rng = np.random.default_rng(20261004 + off)
     done = 0
     for k in range(n_random):
-        b = random_batch(50000 + k, dup_paths=(k % 5 == 0), n_chains=int(rng.choice([1, 4, 9])),
+        b = random_batch(50000 + 1000 * off + k, dup_paths=(k % 5 == 0), n_chains=int(rng.choice([1, 4, 9])),
                          max_bubbles=int(rng.choice([6, 14, 40])), max_reads=int(rng.choice([30, 120, 400])))
         prm = capi.default_params(want_stages=1, min_mapq=int(rng.choice([90, 93, 95])), compaction_mode=int(k % 2),
                                   max_slots=int(rng.choice([0, 0, 1, 3])))
@@ -45,7 +46,7 @@ def main():
             nr = min(nr, 500)
             nb = min(nb, 24)
         nc = 3 if nr > 800 else 6
-        b = capi.synth_batch(n_chains=nc, n_bubbles=nb, n_reads=nr, ploidy=ploidy, seed=7000 + k,
+        b = capi.synth_batch(n_chains=nc, n_bubbles=nb, n_reads=nr, ploidy=ploidy, seed=7000 + 1000 * off + k,
                              mean_span=float(rng.choice([3.0, 7.0, 15.0])), allele_err=float(rng.choice([0.0, 0.02, 0.15])))
         _compare(b, capi.default_params(ploidy=ploidy, want_stages=1, max_slots=int(rng.choice([0, 2])),
                                         switch_cost=float(rng.choice([32.0, 5.0, 0.5])), affine_switch_cost=float(rng.choice([8.0, 0.0, 1.25]))))
