@@ -91,7 +91,7 @@ namespace ahk {
 #define AHK_AT(T, base, i) (((T*)(base))[(unsigned int)(i)])
 #endif
 #define WM_AT(i) AHK_AT(int, Wm, i)
-#define IC_AT(i) AHK_AT(IcPair, IC, i)
+#define IC_AT(i) AHK_AT(IcT, IC, i)  // (IcT: IcPair or IcPair32, a template parameter wherever this is used)
 #define LV_AT(i) AHK_AT(unsigned long long, LV, i)
 #define NZ_AT(i) AHK_AT(unsigned long long, NZ, i)
 
@@ -308,14 +308,15 @@ __device__ __forceinline__ unsigned ic_index(int r, int c, int n) { return (unsi
 // that is consumed four words at a time: the four induced-cost loads of a batch are
 // issued before any of them is used (a load-use pair per loop trip would cost one
 // HBM round trip per word, and a row's live edges sit in 2-4 words).
+template <class IcT>
 __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int lane, const unsigned long long* __restrict__ LV,
-                                             const IcPair* __restrict__ IC, unsigned long long* keys /* F0 P0 F1 P1 */) {
+                                             const IcT* __restrict__ IC, unsigned long long* keys /* F0 P0 F1 P1 */) {
   const unsigned long long bm0 = lane < nw ? LV_AT((unsigned)(r0 * nw + lane)) : 0ull;
   const unsigned long long bm1 = (r1 >= 0 && lane < nw) ? LV_AT((unsigned)(r1 * nw + lane)) : 0ull;
   unsigned long long todo0 = __ballot(bm0 != 0ull), todo1 = __ballot(bm1 != 0ull);
   unsigned long long kF0 = 0, kP0 = 0, kF1 = 0, kP1 = 0;
   while ((todo0 | todo1) != 0ull) {
-    IcPair v[4];
+    IcT v[4];
     int col[4];
     bool second[4];
 #pragma unroll
@@ -366,8 +367,9 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
 }
 
 // rows dlist[0..nd): wave wv takes pairs of rows
+template <class IcT>
 __device__ __forceinline__ void rescan_list(const unsigned short* dlist, int nd, int wv, int lane, int n, int nw,
-                                            const unsigned long long* __restrict__ LV, const IcPair* __restrict__ IC,
+                                            const unsigned long long* __restrict__ LV, const IcT* __restrict__ IC,
                                             unsigned long long* bestF, unsigned long long* bestP) {
   for (int di = 2 * wv; di < nd; di += 8) {
     // (the rows are wave-uniform: as scalars, their address arithmetic runs on the scalar unit)
@@ -564,8 +566,20 @@ __device__ __forceinline__ void tri_seg_wide(const int* __restrict__ Wm, int n, 
 #ifndef AHK_WAVES_PER_SIMD
 #define AHK_WAVES_PER_SIMD 5
 #endif
-__global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
-                                                     int C, int* __restrict__ qhead) {
+// IC32: induced costs as 2 x uint32 (IcPair32).  Exact for a chain whose induced costs provably stay
+// below 2^32: they are sums of non-negative terms, and every term of icf(a,b) / icp(a,b) is at most
+// |W[b][x]| where that is finite and |W[a][x]| where it is not (never both infinite on a live edge),
+// so icf, icp <= S(a) + S(b) with S(r) the sum of the initial |weights| of row r.  Every row scan
+// of the induced costs (single-read separations, rescans) then moves half the HBM sectors; the
+// kernel is bound by those (+10 % at config 3).  A chain that fails the test right after S4b is
+// put on the `deferred` list and left to the 64-bit instance, launched behind this one with that
+// list as its queue (Cdev = its length, on the device).
+template <bool IC32>
+__global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
+                                                       int C, const int* __restrict__ Cdev, int* __restrict__ qhead,
+                                                       int* __restrict__ deferred, int* __restrict__ ndeferred) {
+  using IcT = typename std::conditional<IC32, IcPair32, IcPair>::type;
+  if (Cdev) C = *Cdev;
   extern __shared__ __align__(16) unsigned long long smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   // the wave index as a SCALAR: everything derived from it (the row a wave works on, its
@@ -609,7 +623,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
   __shared__ int s_back;
 
   int* Wm = ws.W + (size_t)blockIdx.x * ws.nmax * ws.nmax;
-  IcPair* IC = ws.IC + (size_t)blockIdx.x * ws.nmax * ws.nmax;
+  IcT* IC = (IcT*)(ws.IC + (size_t)blockIdx.x * ws.nmax * ws.nmax);  // (a slot holds nmax^2 entries of the wide form)
   unsigned long long* LV = ws.live + (size_t)blockIdx.x * ws.nmax * ((ws.nmax + 63) / 64);
   unsigned long long* NZ = ws.nz + (size_t)blockIdx.x * ws.nmax * ((ws.nmax + 63) / 64);
   unsigned int* items_glb = ws.items + (size_t)blockIdx.x * ws.nmax * ws.nmax;
@@ -711,8 +725,10 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
     __syncthreads();
 
     // ================= S4b: similarity matrix W ============================
+    long long smax = 0;  // (this wave's rows) largest row sum of |W|: decides whether 32-bit induced costs are exact
     for (int i = wv; i < n; i += 4) {
       const double si = rates[i], fi = rates[n + i];
+      long long srow = 0;
       for (int j = lane; j < n; j += 64) {
         int q = 0;
         if (j != i) {
@@ -729,13 +745,29 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
         }
         WM_AT((unsigned)(i * n + j)) = q;
         if (m.dump0 >= 0) db.score_dump[m.dump0 + (size_t)i * n + j] = q;
+        srow += q < 0 ? -(long long)q : (long long)q;
+      }
+      if (IC32) {
+        srow = wave_sum_i64(srow);
+        smax = srow > smax ? srow : smax;
       }
     }
+    if (IC32 && lane == 0) s_rk[wv] = (unsigned long long)smax;
     for (int u = tid; u < n; u += kBlock) {
       cl[u] = (unsigned short)u;
       role[u] = ROLE_NONE;
     }
     __syncthreads();
+    if (IC32) {
+      // every induced cost of this chain is at most S(a) + S(b) <= 2 * max row sum: below 2^32, or the chain goes to
+      // the wide instance (uniform: every wave reads the same four values)
+      unsigned long long sm = s_rk[0];
+      for (int k = 1; k < 4; k++) sm = s_rk[k] > sm ? s_rk[k] : sm;
+      if (2ull * sm >= (1ull << 32)) {
+        if (tid == 0) deferred[atomicAdd(ndeferred, 1)] = c;
+        continue;
+      }
+    }
 
 #ifdef AHK_DIAG
     if (lds.stop_after == 1) continue;  // diagnostic build only (results invalid)
@@ -809,7 +841,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             }
           }
           if (act) {
-            IcPair v;
+            IcT v;
             v.f = f;
             v.p = p;
             IC_AT((unsigned)(a * n + b)) = v;
@@ -951,7 +983,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             if (todo != 0ull) todo &= todo - 1ull;
             if (!sub && todo != 0ull) todo &= todo - 1ull;
           }
-          IcPair icv[kFastBatch];
+          IcT icv[kFastBatch];
           int wb[kFastBatch];
           bool on[kFastBatch];
 #pragma unroll
@@ -975,7 +1007,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           for (int c = 0; c < kFastBatch; c++) {
             if (!on[c]) continue;
             const int b = (lw[c] << 6) + lane;
-            IcPair ic = icv[c];
+            IcT ic = icv[c];
             const long long df = (long long)icf_term(W_FORB, wb[c]) - (long long)icf_term(ov, wb[c]);
             const long long dp = (long long)icp_term(W_FORB, wb[c]) - (long long)icp_term(ov, wb[c]);
             if (df != 0 || dp != 0) {
@@ -1288,7 +1320,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           // memory system can deliver them for this access pattern, so the entry (one 128-B
           // line for 16 useful bytes) is loaded only once the delta is known to be non-zero.
 #if !AHK_IC_LATE
-          IcPair ic = IC_AT(ici);
+          IcT ic = IC_AT(ici);
 #endif
           long long df = 0, dp = 0;
 #if defined(AHK_TIMING) && AHK_TIMING > 1
@@ -1363,7 +1395,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
 #endif
           if (df == 0 && dp == 0) return;
 #if AHK_IC_LATE
-          IcPair ic = IC_AT(ici);
+          IcT ic = IC_AT(ici);
 #endif
           ic.f += df;
           ic.p += dp;
@@ -1409,7 +1441,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
             long long df, dp;
             staged_delta(it, df, dp);
             const unsigned ici = ic_index(x, b, n);
-            IcPair ic = IC_AT(ici);
+            IcT ic = IC_AT(ici);
             ic.f += df;
             ic.p += dp;
             IC_AT(ici) = ic;
@@ -1608,7 +1640,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
                 x = (int)((it >> 12) & 0xfffu);
                 const int b = (int)(it & 0xfffu);
                 const unsigned ici = ic_index(x, b, n);
-                IcPair ic = IC_AT(ici);
+                IcT ic = IC_AT(ici);
                 ic.f += df;
                 ic.p += dp;
                 IC_AT(ici) = ic;
@@ -1691,7 +1723,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase(DeviceBatc
           dp = wave_sum_i64(dp);
           if (lane == 0 && (df != 0 || dp != 0)) {
             const unsigned ici = ic_index(x, b, n);
-            IcPair ic = IC_AT(ici);
+            IcT ic = IC_AT(ici);
             ic.f += df;
             ic.p += dp;
             IC_AT(ici) = ic;
@@ -2231,13 +2263,21 @@ size_t phase_lds_bytes(const PhaseLds& l) {
 
 int phase_max_blocks_per_cu(const PhaseLds& l) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_phase, kBlock, phase_lds_bytes(l)) != hipSuccess) return 1;
+  int nb32 = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_phase_t<false>, kBlock, phase_lds_bytes(l)) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb32, k_phase_t<true>, kBlock, phase_lds_bytes(l)) != hipSuccess) return 1;
+  if (nb32 < nb) nb = nb32;
   return nb < 1 ? 1 : nb;
 }
 
-void launch_phase(const DeviceBatch& db, const SlotWorkspace& ws, const PhaseLds& l, const int* queue, int C, int* qhead,
+void launch_phase(const DeviceBatch& db, const SlotWorkspace& ws, const PhaseLds& l, const int* queue, int C, int* ctl, int* deferred,
                   int slots, hipStream_t stream) {
-  hipLaunchKernelGGL(k_phase, dim3(slots), dim3(kBlock), phase_lds_bytes(l), stream, db, ws, l, queue, C, qhead);
+  // narrow induced costs first; the chains it had to defer (none in the BASELINE configurations 1-3 and 5) go
+  // through the wide instance, whose workgroups find an empty list otherwise
+  hipLaunchKernelGGL(k_phase_t<true>, dim3(slots), dim3(kBlock), phase_lds_bytes(l), stream, db, ws, l, queue, C, (const int*)nullptr, ctl, deferred,
+                     ctl + 2);
+  hipLaunchKernelGGL(k_phase_t<false>, dim3(slots), dim3(kBlock), phase_lds_bytes(l), stream, db, ws, l, (const int*)deferred, 0,
+                     (const int*)(ctl + 2), ctl + 1, (int*)nullptr, (int*)nullptr);
 }
 
 }  // namespace ahk

@@ -79,7 +79,8 @@ struct PhaseClass {
   PhaseLds pl{};
   SlotWorkspace ws{};
   int* queue = nullptr;  // device: this class's chains, most expensive first
-  int* qhead = nullptr;  // device: atomic cursor
+  int* qhead = nullptr;  // device: three ints -- cursor of the queue, cursor of the deferred list, length of the deferred list
+  int* deferred = nullptr;  // device [count]: chains the narrow (32-bit induced cost) instance of k_phase leaves to the wide one
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
 };
@@ -663,7 +664,7 @@ static int build_classes(ahsoka_device_batch* h) {
     return AHSOKA_OK;
   };
   int rc = AHSOKA_OK;
-  if ((rc = wsalloc(&h->qheads, h->classes.size()))) { free_classes(h); return rc; }
+  if ((rc = wsalloc(&h->qheads, 3 * h->classes.size()))) { free_classes(h); return rc; }
   size_t ki = 0, mi = 0;
   for (PhaseClass& pc : h->classes) {
     while (members[mi].empty()) mi++;
@@ -672,13 +673,13 @@ static int build_classes(ahsoka_device_batch* h) {
       const double ca = (double)nfin[a] * nfin[a] * h->meta[(size_t)a].B, cb = (double)nfin[b] * nfin[b] * h->meta[(size_t)b].B;
       return ca > cb;
     });
-    pc.qhead = h->qheads + ki++;
+    pc.qhead = h->qheads + 3 * ki++;
     SlotWorkspace& ws = pc.ws;
     ws.nmax = pc.nmax;
     ws.Pmax = pc.Pmax;
     ws.Tmax = Tmax;
     const size_t S = (size_t)pc.slots, nn = (size_t)ws.nmax * ws.nmax, words = (size_t)ws.nmax * ((ws.nmax + 63) / 64);
-    if ((rc = wsalloc(&pc.queue, q.size())) || (rc = wsalloc(&ws.W, S * nn)) || (rc = wsalloc(&ws.IC, S * nn)) ||
+    if ((rc = wsalloc(&pc.queue, q.size())) || (rc = wsalloc(&pc.deferred, q.size())) || (rc = wsalloc(&ws.W, S * nn)) || (rc = wsalloc(&ws.IC, S * nn)) ||
         (rc = wsalloc(&ws.live, S * words)) || (rc = wsalloc(&ws.nz, S * words)) || (rc = wsalloc(&ws.items, S * nn)) ||
         (rc = wsalloc(&ws.rates, S * 2 * ws.nmax)) || (rc = wsalloc(&ws.tp_k, S * ws.Pmax)) ||
         (rc = wsalloc(&ws.tp_gcid, S * ws.Pmax * 8)) || (rc = wsalloc(&ws.tp_cov, S * ws.Pmax * 8)) ||
@@ -717,18 +718,18 @@ extern "C" int ahsoka_phase_device(ahsoka_device_batch* h) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (int rc = build_classes(h)) return rc;
   }
-  if (!h->classes.empty()) HIP_TRY(hipMemsetAsync(h->qheads, 0, h->classes.size() * sizeof(int), h->stream));
+  if (!h->classes.empty()) HIP_TRY(hipMemsetAsync(h->qheads, 0, 3 * h->classes.size() * sizeof(int), h->stream));
   HIP_TRY(hipEventRecord(h->ev[1], h->stream));
   if (h->classes.size() == 1) {
     PhaseClass& pc = h->classes[0];
-    launch_phase(h->db, pc.ws, pc.pl, pc.queue, pc.count, pc.qhead, pc.slots, h->stream);
+    launch_phase(h->db, pc.ws, pc.pl, pc.queue, pc.count, pc.qhead, pc.deferred, pc.slots, h->stream);
     HIP_TRY(hipGetLastError());
   } else {
     // one launch per size class, each on its own stream: they share the CUs, the
     // class of the largest chains first in line
     for (PhaseClass& pc : h->classes) {
       HIP_TRY(hipStreamWaitEvent(pc.stream, h->ev[1], 0));
-      launch_phase(h->db, pc.ws, pc.pl, pc.queue, pc.count, pc.qhead, pc.slots, pc.stream);
+      launch_phase(h->db, pc.ws, pc.pl, pc.queue, pc.count, pc.qhead, pc.deferred, pc.slots, pc.stream);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(pc.done, pc.stream));
       HIP_TRY(hipStreamWaitEvent(h->stream, pc.done, 0));

@@ -21,6 +21,12 @@ constexpr int32_t W_FORB = -0x7fffffff;  // -INT_MAX: its negation is W_PERM
 struct alignas(16) IcPair {  // induced cost of forbidding / of making permanent
   long long f, p;
 };
+// the same in 32 bits (induced costs are sums of non-negative terms: unsigned), for chains whose induced
+// costs provably stay below 2^32 (k_phase decides per chain from the row sums of |W|): half the sectors
+// of every row scan of the induced costs
+struct alignas(8) IcPair32 {
+  unsigned int f, p;
+};
 
 // per-chain description, computed on the host at upload
 struct ChainMeta {
@@ -135,7 +141,9 @@ size_t readset_lds2_bytes(const ReadsetLds2& l);
 void launch_readset(const DeviceBatch& db, const int* list, int count, const ReadsetLds& l, hipStream_t stream);
 void launch_readset_lds(const DeviceBatch& db, const int* list, int count, const ReadsetLds2& l, hipStream_t stream);
 size_t phase_lds_bytes(const PhaseLds& l);
-void launch_phase(const DeviceBatch& db, const SlotWorkspace& ws, const PhaseLds& l, const int* queue, int C, int* qhead,
+// ctl: three device ints of the class -- cursor of the queue, cursor of the deferred list, length of the
+// deferred list -- zeroed by the caller before every call; deferred: [C] device ints
+void launch_phase(const DeviceBatch& db, const SlotWorkspace& ws, const PhaseLds& l, const int* queue, int C, int* ctl, int* deferred,
                   int slots, hipStream_t stream);
 int phase_max_blocks_per_cu(const PhaseLds& l);
 }  // namespace ahk

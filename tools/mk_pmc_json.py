@@ -9,7 +9,8 @@ for line in open(f"gpurun_out/{tag}_pmc.txt"):
         name = next((n for n in ("k_phase", "k_readset_lds", "k_readset", "k_sortperm") if n + "(" in p[1] or p[1].endswith(n)), None)
         if name is None:
             name = "k_phase" if "k_phase" in p[1] else ("k_sortperm" if "k_sortperm" in p[1] else ("k_readset_lds" if "k_readset_lds" in p[1] else "k_readset"))
-        k.setdefault(name, {})[p[0] + "_KB"] = float(p[3])
+        d = k.setdefault(name, {})
+        d[p[0] + "_KB"] = d.get(p[0] + "_KB", 0.0) + float(p[3])  # (k_phase runs as two instances: narrow and wide induced costs)
 for v in k.values():
     v["hbm_bytes_raw"] = (v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024
     v["hbm_bytes_fetch_x2"] = (2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024
