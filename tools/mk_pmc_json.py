@@ -5,7 +5,8 @@ tag, config, chains = sys.argv[1], sys.argv[2], int(sys.argv[3])
 k = {}
 for line in open(f"gpurun_out/{tag}_pmc.txt"):
     p = line.split()
-    if len(p) == 4 and p[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+    if len(p) >= 4 and p[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+        p = [p[0], " ".join(p[1:-2]), p[-2], p[-1]]  # (a templated kernel's name starts with "void ": it has a blank)
         name = next((n for n in ("k_phase", "k_readset_lds", "k_readset", "k_sortperm") if n + "(" in p[1] or p[1].endswith(n)), None)
         if name is None:
             name = "k_phase" if "k_phase" in p[1] else ("k_sortperm" if "k_sortperm" in p[1] else ("k_readset_lds" if "k_readset_lds" in p[1] else "k_readset"))
