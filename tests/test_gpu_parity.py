@@ -529,3 +529,16 @@ def test_device_result_block_matches_download():
     np.testing.assert_array_equal(pos_off, res.pos_off)
     np.testing.assert_array_equal(pos, res.pos)
     np.testing.assert_array_equal(hap, res.hap_allele)
+
+
+def test_wide_induced_costs_instance():
+    """k_phase keeps induced costs as 2 x uint32 where a chain's row sums of |W| prove them below 2^32
+    and defers the other chains to its 64-bit instance.  1800 error-free reads over 16 bubbles with
+    long spans give ~1170 final reads whose largest row sum is 2^31.7: this chain takes the wide
+    instance (every other test and configuration takes the narrow one), two of them through one slot."""
+    b = capi.synth_batch(n_chains=2, n_bubbles=16, n_reads=1800, ploidy=2, seed=12, mean_span=15.0, allele_err=0.0)
+    g, o = _compare(b, capi.default_params(want_stages=1, max_slots=1))
+    assert (g.status == capi.ST_PHASED).all()
+    n = int(o.n_reads[0])
+    w = np.asarray(o.stages["score_q"][: n * n], dtype=np.int64).reshape(n, n)
+    assert 2 * int(np.abs(w).sum(axis=1).max()) >= 1 << 32  # (the premise: this chain must be deferred)
