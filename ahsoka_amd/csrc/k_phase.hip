@@ -308,6 +308,10 @@ __device__ __forceinline__ unsigned ic_index(int r, int c, int n) { return (unsi
 // that is consumed four words at a time: the four induced-cost loads of a batch are
 // issued before any of them is used (a load-use pair per loop trip would cost one
 // HBM round trip per word, and a row's live edges sit in 2-4 words).
+#ifndef AHK_RESCAN_BATCH
+#define AHK_RESCAN_BATCH 4
+#endif
+constexpr int kRescanBatch = AHK_RESCAN_BATCH;  // bitmap words of a rescan whose induced costs are requested together
 template <class IcT>
 __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int lane, const unsigned long long* __restrict__ LV,
                                              const IcT* __restrict__ IC, unsigned long long* keys /* F0 P0 F1 P1 */) {
@@ -316,11 +320,11 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
   unsigned long long todo0 = __ballot(bm0 != 0ull), todo1 = __ballot(bm1 != 0ull);
   unsigned long long kF0 = 0, kP0 = 0, kF1 = 0, kP1 = 0;
   while ((todo0 | todo1) != 0ull) {
-    IcT v[4];
-    int col[4];
-    bool second[4];
+    IcT v[kRescanBatch];
+    int col[kRescanBatch];
+    bool second[kRescanBatch];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < kRescanBatch; c++) {
       col[c] = -1;
       second[c] = false;
       v[c].f = 0;  // (defined on every path: an undefined value becomes a register that lives across the caller's loop)
@@ -343,7 +347,7 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
       }
     }
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < kRescanBatch; c++) {
       if (col[c] < 0) continue;
       const int rr = second[c] ? r1 : r0;
       const unsigned long long k1 = mkkey(v[c].f, rr, col[c]), k2 = mkkey(v[c].p, rr, col[c]);
