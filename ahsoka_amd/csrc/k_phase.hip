@@ -283,6 +283,13 @@ __device__ __forceinline__ void fold_rows_grouped(bool act, int x, unsigned long
   }
 }
 
+// does the one triangle (y, rs, b) of a staged-row edge change its induced costs?  ov = W[rs][y] (old
+// weight of the pair that is rewritten to +-infinity), wb = W[rs][b] (third edge)
+__device__ __forceinline__ bool staged_changes(int ov, int wb, bool perm) {
+  if (perm) return icf_term(W_PERM, wb) != icf_term(ov, wb) || icp_term(W_PERM, wb) != icp_term(ov, wb);
+  return icf_term(W_FORB, wb) != icf_term(ov, wb) || icp_term(W_FORB, wb) != icp_term(ov, wb);
+}
+
 // is the pair (role r1, role r2) rewritten by this iteration, and to what:
 // bit (r1*5 + r2) of a 25-bit table
 constexpr unsigned int pair_bit(int r1, int r2) { return 1u << (r1 * 5 + r2); }
@@ -1122,6 +1129,13 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
       const int nA = __builtin_amdgcn_readfirstlane(s_cnt[0]), nB = __builtin_amdgcn_readfirstlane(s_cnt[1]);
       const int nFa = __builtin_amdgcn_readfirstlane(s_cnt[2]), nFb = __builtin_amdgcn_readfirstlane(s_cnt[3]);
       const int nT = nA + nB + nFa + nFb;
+      // Edges priced from the staged row (the far end b is not rewritten itself, the row's only member
+      // list is {rs}): roles whose rows qualify
+      unsigned int ldsrole = 0u;
+      if (rs >= 0) {
+        if (rs == eu) ldsrole = (nFa == 0 ? 1u << ROLE_B : 0u) | (1u << ROLE_FB);
+        else ldsrole = (nFb == 0 ? 1u << ROLE_A : 0u) | (1u << ROLE_FA);
+      }
 #ifdef AHK_TIMING
       heavy_it = (nA + nFa > 64 && nB + nFb <= 1) || (nB + nFb > 64 && nA + nFa <= 1);
       nheavy += heavy_it ? 1 : 0;
@@ -1231,6 +1245,39 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
             const unsigned long long nzc = rx == ROLE_A ? (oB | oFb) : rx == ROLE_B ? (oA | oFa) : rx == ROLE_FA ? oB : oA;
             cand = lvn & (nzc | Tm) & ~(Tm & low);
           }
+          // Staged-row rows: their candidates are priced right here, from the row in LDS, and only
+          // the 8 % that change are listed at all (the list, its overflow to HBM and the classifying
+          // pass shrink accordingly).  Sparse words by their own lane, dense words by the whole wave.
+          if (ldsrole != 0u) {  // uniform
+            const bool elig = x >= 0 && wordok && ((ldsrole >> rx) & 1u);
+            const unsigned long long cs = elig ? (cand & ~Tm) : 0ull;
+            const int pcs = __popcll(cs);
+            const bool perm = merge && (rx == ROLE_A || rx == ROLE_B);
+            unsigned long long surv = 0ull;
+            if (pcs > 0 && pcs <= kLaneExpandMax) {
+              const int ov = wrow[x];
+              unsigned long long mbits = cs;
+              while (mbits != 0ull) {
+                const int bit = __builtin_ctzll(mbits);
+                mbits &= mbits - 1ull;
+                if (staged_changes(ov, wrow[(kw << 6) + bit], perm)) surv |= 1ull << bit;
+              }
+            }
+            unsigned long long todoS = __ballot(pcs > kLaneExpandMax);
+            while (todoS != 0ull) {
+              const int l = __builtin_ctzll(todoS);
+              todoS &= todoS - 1ull;
+              const unsigned long long w = readlane_u64(cs, l);
+              const int xl = __builtin_amdgcn_readlane(x, l);
+              const bool perml = __builtin_amdgcn_readlane((int)perm, l) != 0;
+              const int kwl = l & (nwp - 1);
+              bool ch = false;
+              if ((w >> lane) & 1ull) ch = staged_changes(wrow[xl], wrow[(kwl << 6) + lane], perml);
+              const unsigned long long bal = __ballot(ch);
+              if (lane == l) surv = bal;
+            }
+            if (elig) cand = surv | (cand & Tm);
+          }
           // Item slots by an exclusive scan of the popcounts (order: lane = (row, word),
           // then bit -- the same as a word-by-word walk).  Sparse words (the rule late
           // in a chain: 2-3 live edges per word) are expanded by their own lane, all
@@ -1309,13 +1356,6 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
 #if defined(AHK_TIMING) && AHK_TIMING == 1
         AHK_T(8);  // (level 1: "decode" = heavy-list building, "tri" = the plain loop, P3b = the heavy pass)
 #endif
-        // Edges priced from the staged row (rb == NONE, the row's only member list is {rs}):
-        // roles whose rows qualify
-        unsigned int ldsrole = 0u;
-        if (rs >= 0) {
-          if (rs == eu) ldsrole = (nFa == 0 ? 1u << ROLE_B : 0u) | (1u << ROLE_FB);
-          else ldsrole = (nFb == 0 ? 1u << ROLE_A : 0u) | (1u << ROLE_FA);
-        }
         // any other edge: its triangles from HBM, applied at once
         auto plain_item = [&](const unsigned int it, const int rx, const int rb) {
           const int x = (int)((it >> 12) & 0xfffu), b = (int)(it & 0xfffu);
@@ -1475,9 +1515,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
               hv = ((heavy >> rx) & 1u) && rb == ROLE_NONE;
               if (!hv) {
                 if (((ldsrole >> rx) & 1u) && rb == ROLE_NONE) {
-                  long long df, dp;
-                  staged_delta(it, df, dp);
-                  chg = df != 0 || dp != 0;
+                  chg = true;  // (P3a lists a staged-row edge only if its induced costs change)
                 } else {
                   sl = true;
                 }
