@@ -1254,16 +1254,20 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
             const int pcs = __popcll(cs);
             const bool perm = merge && (rx == ROLE_A || rx == ROLE_B);
             unsigned long long surv = 0ull;
-            if (pcs > 0 && pcs <= kLaneExpandMax) {
-              const int ov = wrow[x];
+            // (a pair that becomes permanent from a weight <= 0, or forbidden from a weight > 0, changes the
+            // induced costs of EVERY candidate -- all have a non-zero third edge: no test per column needed)
+            const int ovx = pcs > 0 ? wrow[x] : 0;
+            const bool all = pcs > 0 && (perm ? ovx <= 0 : ovx > 0);
+            if (all) surv = cs;
+            if (pcs > 0 && !all && pcs <= kLaneExpandMax) {
               unsigned long long mbits = cs;
               while (mbits != 0ull) {
                 const int bit = __builtin_ctzll(mbits);
                 mbits &= mbits - 1ull;
-                if (staged_changes(ov, wrow[(kw << 6) + bit], perm)) surv |= 1ull << bit;
+                if (staged_changes(ovx, wrow[(kw << 6) + bit], perm)) surv |= 1ull << bit;
               }
             }
-            unsigned long long todoS = __ballot(pcs > kLaneExpandMax);
+            unsigned long long todoS = __ballot(pcs > kLaneExpandMax && !all);
             while (todoS != 0ull) {
               const int l = __builtin_ctzll(todoS);
               todoS &= todoS - 1ull;
