@@ -62,6 +62,8 @@ class CPhaseParams(C.Structure):
         ("device", C.c_int32),
         ("want_stages", C.c_int32),
         ("max_slots", C.c_int32),
+        ("symmetry_opt", C.c_int32),
+        ("row_limit", C.c_int32),
     ]
 
 
@@ -112,6 +114,7 @@ ABI_SYMBOLS = [
     "ahsoka_batch_free", "ahsoka_batch_result_device", "ahsoka_batch_kernel_times", "ahsoka_batch_bytes", "ahsoka_render_chain",
     "ahsoka_ingest", "ahsoka_ingest_dump", "ahsoka_batch_host_free", "ahsoka_synth_batch", "ahsoka_synth_select", "ahsoka_synth_shapes", "ahsoka_synth_write_text", "ahsoka_synth_truth",
     "ahsoka_test_introsort_u32", "ahsoka_test_introsort_par_u32", "ahsoka_test_detlog",
+    "ahsoka_test_multi_plan",
 ]
 
 _lib = None
@@ -161,6 +164,8 @@ def lib() -> C.CDLL:
     L.ahsoka_test_introsort_par_u32.argtypes = [C.POINTER(C.c_uint32), C.c_int32]
     L.ahsoka_test_detlog.argtypes = [C.c_double]
     L.ahsoka_test_detlog.restype = C.c_double
+    L.ahsoka_test_multi_plan.argtypes = [C.POINTER(CChainBatch), C.POINTER(CPhaseParams), C.c_int32, i32p, i32p,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32]
     _lib = L
     return L
 
@@ -440,6 +445,18 @@ def phase_batch_multi(batch: ChainBatch, devices, params: Optional[CPhaseParams]
         return result_from_c(r)
     finally:
         lib().ahsoka_result_free(C.byref(r))
+
+
+def multi_plan(batch: ChainBatch, n_devices: int, params: Optional[CPhaseParams] = None, check: bool = True):
+    """The static partition ahsoka_phase_batch_multi would use, without touching a device:
+    (owner [C], blocks?, serial prologue ms, longest per-shard host ms)."""
+    prm = params if params is not None else default_params()
+    owner = np.zeros(max(1, batch.n_chains), dtype=np.int32)
+    blocks = C.c_int32(0)
+    serial, shard = C.c_double(0), C.c_double(0)
+    _check(lib().ahsoka_test_multi_plan(batch.ptr(), C.byref(prm), n_devices, owner.ctypes.data_as(i32p), C.byref(blocks),
+                                        C.byref(serial), C.byref(shard), 1 if check else 0), "ahsoka_test_multi_plan")
+    return owner[:batch.n_chains], bool(blocks.value), float(serial.value), float(shard.value)
 
 
 class DeviceBatch:

@@ -266,7 +266,10 @@ struct Graph {
   // and the walk itself stops after kMaxAllelePaths paths: a bubble with more alleles than the
   // device handles (16, phase_kernels.h) makes its chain AHSOKA_ST_UNSUPPORTED anyway, so the
   // hot path never sees a truncated list as if it were complete.  Up to the bound the listing
-  // is the reference's, path for path, in order (tests/golden/sbub.ref.txt).
+  // is the reference's, path for path, in order (tests/golden/sbub.ref.txt).  A listing that was
+  // cut is SAID to be cut: allele_paths reports it, the ingest warns on stderr and the dump
+  // (ahsoka_ingest_dump) carries a TRUNCATED line after the bubble's ALLELE lines -- the
+  // reference would have listed every path.
   static constexpr size_t kMaxAllelePaths = 1024;
 
   size_t count_paths(const GBubble& b, int nid, int dirflag, std::unordered_map<long long, size_t>* memo,
@@ -313,8 +316,9 @@ struct Graph {
     }
   }
 
-  std::vector<std::vector<int>> allele_paths(const GBubble& b) {
+  std::vector<std::vector<int>> allele_paths(const GBubble& b, bool* truncated = nullptr) {
     std::vector<std::vector<int>> paths;
+    if (truncated) *truncated = false;
     if (b.inner.size() == 2) {
       for (int x : b.inner) paths.push_back({b.source, x, b.sink});
       return paths;
@@ -331,6 +335,9 @@ struct Graph {
     }
     std::vector<int> seq;
     dfs_paths(b, b.sink, dirflag, &seq, &paths);
+    // (the count is only a hint where the walk's revisit rule decides -- cycles --; what says
+    // "cut" is the walk itself having stopped at the bound)
+    if (truncated) *truncated = paths.size() >= kMaxAllelePaths;
     return paths;
   }
 
@@ -534,7 +541,9 @@ extern "C" int ahsoka_ingest_dump(const char* gfa_path, const char* gaf_path, co
     for (auto& oc : order) {
       const GChain& ch = g.chains[(size_t)oc.second];
       for (const GBubble& b : ch.bubbles) {
-        std::vector<std::vector<int>> paths = g.allele_paths(b);
+        bool cut = false;
+        std::vector<std::vector<int>> paths = g.allele_paths(b, &cut);
+        if (cut) std::fprintf(stderr, "ahsoka: chain %d bubble %d has more than %zu allele paths: listing truncated\n", ch.id, b.id, paths.size());
         for (size_t a = 0; a < paths.size(); a++) {
           std::fprintf(f, "ALLELE %d %d %zu %zu", ch.id, b.id, a, paths[a].size());
           for (int nd : paths[a]) std::fprintf(f, " %d", nd);
@@ -542,6 +551,7 @@ extern "C" int ahsoka_ingest_dump(const char* gfa_path, const char* gaf_path, co
           for (size_t i = 0; i + 1 < paths[a].size(); i++) std::fprintf(f, " %c", g.step_sign(paths[a][i], paths[a][i + 1]));
           std::fprintf(f, "\n");
         }
+        if (cut) std::fprintf(f, "TRUNCATED %d %d %zu\n", ch.id, b.id, paths.size());
       }
     }
     // per chain (ascending id): one ALN line per GAF line, with the number of copies
@@ -663,7 +673,12 @@ extern "C" int ahsoka_ingest(const char* gfa_path, const char* gaf_path, ahsoka_
         local_of(b.sink);
       }
       for (const GBubble& b : ch.bubbles) {
-        for (const std::vector<int>& p : g.allele_paths(b)) {
+        bool cut = false;
+        const std::vector<std::vector<int>> bpaths = g.allele_paths(b, &cut);
+        if (cut)  // (more alleles than the device limit anyway: the chain comes back AHSOKA_ST_UNSUPPORTED)
+          std::fprintf(stderr, "ahsoka: chain %d bubble %d has more than %zu allele paths: listing truncated, chain will not be phased\n",
+                       ch.id, b.id, bpaths.size());
+        for (const std::vector<int>& p : bpaths) {
           for (size_t i = 0; i < p.size(); i++) {
             hb->apath_node.push_back(local_of(p[i]));
             hb->apath_sign.push_back(i + 1 < p.size() ? (uint8_t)g.step_sign(p[i], p[i + 1]) : (uint8_t)'+');

@@ -632,6 +632,9 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, Reads
     }
     return;
   }
+  // the scalars above are written by other waves from here on (s_anydup in the mask loop below,
+  // s_maxpos / s_any / s_n later): their initialisation must have landed first
+  __syncthreads();
 
 #ifdef AHK_RS_TIMING
   long long rs_t[8], rs_last = (long long)clock64();

@@ -15,6 +15,7 @@
 #include <new>
 #include <numeric>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -145,6 +146,8 @@ extern "C" void ahsoka_default_params(ahsoka_phase_params* prm) {
   prm->device = 0;
   prm->want_stages = 0;
   prm->max_slots = 0;
+  prm->symmetry_opt = 0;  // HaploThreader(ploidy, 32.0, 8.0, false, 0), :320
+  prm->row_limit = 0;
 }
 
 extern "C" int ahsoka_abi_version(void) { return AHSOKA_ABI_VERSION; }
@@ -225,12 +228,28 @@ int ahk::validate_batch(const ahsoka_chain_batch* in) {
   return bad ? AHSOKA_E_ARG : AHSOKA_OK;
 }
 
-extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_phase_params* prm,
-                                   ahsoka_device_batch** handle) {
+namespace {
+// joins a host thread on every way out of a scope, exceptions included (a joinable std::thread
+// that is destroyed calls std::terminate)
+struct JoinGuard {
+  std::thread& t;
+  ~JoinGuard() {
+    if (t.joinable()) t.join();
+  }
+};
+}  // namespace
+
+// (*hp is set as soon as the handle exists, so that the extern "C" wrapper can release it when a
+// host allocation throws)
+static int upload_impl(const ahsoka_chain_batch* in, const ahsoka_phase_params* prm, ahsoka_device_batch** handle,
+                       ahsoka_device_batch** hp) {
   if (!in || !prm || !handle) return AHSOKA_E_ARG;
   if (prm->ploidy < 2 || prm->ploidy > kMaxPloidy || prm->min_overlap < 0 || prm->max_slots < 0) return AHSOKA_E_ARG;
   // (threading scores must be non-negative: the device argmin orders them by their bit patterns)
   if (!(prm->switch_cost >= 0.0) || !(prm->affine_switch_cost >= 0.0)) return AHSOKA_E_ARG;
+  // the threader's symmetryOptimization / rowLimit exist at the boundary so that it mirrors :320
+  // completely; only the reference's literals (false, 0) are implemented
+  if (prm->symmetry_opt != 0 || prm->row_limit != 0) return AHSOKA_E_UNSUPPORTED;
   if (int e = ahk::validate_batch(in)) return e;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return AHSOKA_E_NODEVICE;
@@ -239,15 +258,26 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
 
   ahsoka_device_batch* h = new (std::nothrow) ahsoka_device_batch();
   if (!h) return AHSOKA_E_NOMEM;
+  *hp = h;
   h->prm = *prm;
   h->device = prm->device;
   const int C = h->C = in->n_chains;
   std::memset(&h->db, 0, sizeof(h->db));
   int rc = AHSOKA_OK;
+  struct RawCopy {
+    void* dst;
+    const void* src;
+    size_t bytes;
+  };
+  // (declared before the copier and its guard: the thread reads them until it is joined)
+  std::vector<RawCopy> raw;
+  std::atomic<int> copy_rc{AHSOKA_OK};
   std::thread copier;
+  JoinGuard copier_guard{copier};
   auto fail = [&](int code) {
     if (copier.joinable()) copier.join();
     ahsoka_batch_free(h);
+    *hp = nullptr;
     return code;
   };
   hipDeviceProp_t prop;
@@ -261,12 +291,6 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   DeviceBatch& db = h->db;
   const long long SB = in->bubble_off[C], SA = in->allele_off[SB], SP = in->apath_off[SA], SR = in->read_off[C],
                   SL = in->rnode_off[SR];
-  struct RawCopy {
-    void* dst;
-    const void* src;
-    size_t bytes;
-  };
-  std::vector<RawCopy> raw;
   auto stage = [&](auto** out, const auto* src, size_t count) -> int {
     typename std::remove_const<typename std::remove_pointer<decltype(src)>::type>::type* p = nullptr;
     if (int e = h->dalloc(&p, count)) return e;
@@ -289,7 +313,6 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
     if ((rc = stage(&db.read_flags, (const unsigned char*)in->read_flags, (size_t)SR))) return fail(rc);
   if (in->s1_order)
     if ((rc = stage(&db.s1_order, (const int*)in->s1_order, (size_t)SB))) return fail(rc);
-  std::atomic<int> copy_rc{AHSOKA_OK};
   copier = std::thread([&raw, &copy_rc, dev = prm->device] {
     if (hipSetDevice(dev) != hipSuccess) {
       copy_rc = AHSOKA_E_NODEVICE;
@@ -521,6 +544,25 @@ extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_ph
   return AHSOKA_OK;
 }
 
+// No exception crosses the C ABI: a failed host allocation (or a thread that cannot be started)
+// becomes an error code, and whatever the call had built is released.
+#define AHSOKA_GUARDED(call, cleanup)          \
+  try {                                        \
+    return call;                               \
+  } catch (const std::bad_alloc&) {            \
+    cleanup;                                   \
+    return AHSOKA_E_NOMEM;                     \
+  } catch (...) {                              \
+    cleanup;                                   \
+    return AHSOKA_E_HIP;                       \
+  }
+
+extern "C" int ahsoka_batch_upload(const ahsoka_chain_batch* in, const ahsoka_phase_params* prm,
+                                   ahsoka_device_batch** handle) {
+  ahsoka_device_batch* h = nullptr;
+  AHSOKA_GUARDED(upload_impl(in, prm, handle, &h), if (h) ahsoka_batch_free(h));
+}
+
 // The per-slot state of k_phase (W, IC, bitmaps: ~24 B per read pair) is sized by
 // the FINAL readsets, which are only known after k_readset has run (reads are
 // filtered by identity and variant count: ~600 of 1000 survive at config 3).
@@ -705,7 +747,7 @@ static int build_classes(ahsoka_device_batch* h) {
   return AHSOKA_OK;
 }
 
-extern "C" int ahsoka_phase_device(ahsoka_device_batch* h) {
+static int phase_device_impl(ahsoka_device_batch* h) {
   if (!h) return AHSOKA_E_ARG;
   HIP_TRY(hipSetDevice(h->device));
   if (h->C == 0) return AHSOKA_OK;
@@ -716,6 +758,10 @@ extern "C" int ahsoka_phase_device(ahsoka_device_batch* h) {
   HIP_TRY(hipGetLastError());
   if (!h->ws_ready) {  // first call only: size classes and slot pools from the real readsets
     HIP_TRY(hipStreamSynchronize(h->stream));
+    // (shards that share a device ordinal -- a device list may repeat one -- size their slot pools
+    // one after the other: each takes its 60 % of what the previous one left)
+    static std::mutex ws_mutex[64];
+    std::lock_guard<std::mutex> lk(ws_mutex[h->device & 63]);
     if (int rc = build_classes(h)) return rc;
   }
   if (!h->classes.empty()) HIP_TRY(hipMemsetAsync(h->qheads, 0, 3 * h->classes.size() * sizeof(int), h->stream));
@@ -741,6 +787,11 @@ extern "C" int ahsoka_phase_device(ahsoka_device_batch* h) {
   HIP_TRY(hipEventElapsedTime(&h->k_ms[1], h->ev[1], h->ev[2]));
   h->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return AHSOKA_OK;
+}
+
+extern "C" int ahsoka_phase_device(ahsoka_device_batch* h) {
+  // (a slot workspace half built when a host allocation throws is released; the next call rebuilds it)
+  AHSOKA_GUARDED(phase_device_impl(h), if (h && !h->ws_ready) free_classes(h));
 }
 
 extern "C" int ahsoka_batch_result_device(ahsoka_device_batch* h, void** dev_ptr, int64_t* n_int32) {
@@ -783,7 +834,7 @@ int fetch(std::vector<T>& dst, const T* src, size_t count) {
 }
 }  // namespace
 
-extern "C" int ahsoka_batch_download(ahsoka_device_batch* h, ahsoka_phase_result* out) {
+static int download_impl(ahsoka_device_batch* h, ahsoka_phase_result* out) {
   if (!h || !out) return AHSOKA_E_ARG;
   HIP_TRY(hipSetDevice(h->device));
   std::memset(out, 0, sizeof(*out));
@@ -865,9 +916,29 @@ extern "C" int ahsoka_batch_download(ahsoka_device_batch* h, ahsoka_phase_result
     out->score_off = hostdup(score_off);
     out->score_q = hostdup(osc);
   }
+  // hostdup is a plain malloc: a failed one must not come back as AHSOKA_OK with a NULL array
+  bool ok = out->status && out->pos_off && out->pos && out->hap_allele && out->hap_cluster && out->n_reads && out->n_clusters &&
+            out->n_iterations;
+  if (h->prm.want_stages)
+    ok = ok && out->vmat_off && out->vfull && out->vpart && out->fread_off && out->fread_name && out->fread_cluster && out->score_off &&
+         out->score_q;
+  if (!ok) return AHSOKA_E_NOMEM;  // (the wrapper releases what was allocated)
   out->elapsed_ms = h->last_ms;
   out->kernel_ms = (double)h->k_ms[0] + (double)h->k_ms[1];
   return AHSOKA_OK;
+}
+
+extern "C" int ahsoka_batch_download(ahsoka_device_batch* h, ahsoka_phase_result* out) {
+  int rc;
+  try {
+    rc = download_impl(h, out);
+  } catch (const std::bad_alloc&) {
+    rc = AHSOKA_E_NOMEM;
+  } catch (...) {
+    rc = AHSOKA_E_HIP;
+  }
+  if (rc != AHSOKA_OK && rc != AHSOKA_E_ARG && out) ahsoka_result_free(out);  // (zeroes *out as well)
+  return rc;
 }
 
 extern "C" void ahsoka_batch_free(ahsoka_device_batch* h) {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AHSOKA_ABI_VERSION 2
+#define AHSOKA_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------- */
 #define AHSOKA_OK 0
@@ -135,6 +135,11 @@ typedef struct ahsoka_phase_params {
                                  per size class (workgroups of the persistent grid, each
                                  with its own slot of HBM working state): a memory knob;
                                  results do not depend on it                          */
+  int32_t symmetry_opt;       /* HaploThreader's symmetryOptimization: reference literal
+                                 false (alignmentstoreadset.cpp:320).  Only 0 is implemented;
+                                 anything else is rejected with AHSOKA_E_UNSUPPORTED      */
+  int32_t row_limit;          /* HaploThreader's rowLimit: reference literal 0 = unlimited
+                                 (:320).  Only 0 is implemented (AHSOKA_E_UNSUPPORTED)    */
 } ahsoka_phase_params;
 
 /*
@@ -280,6 +285,14 @@ int ahsoka_test_introsort_u32(uint32_t* keys_hi16_payload_lo16, int32_t n);
 /* the rank-based (parallelisable) statement of the same sort: must give the same permutation */
 int ahsoka_test_introsort_par_u32(uint32_t* keys_hi16_payload_lo16, int32_t n);
 double ahsoka_test_detlog(double x);
+/* the static partition of ahsoka_phase_batch_multi and the per-shard host work up to the first
+ * upload, without touching a device: owner_out [C] or NULL; *blocks_out 1 = contiguous blocks
+ * (views of the caller's arrays), 0 = LPT (packed copies); *serial_ms = cost model + partition,
+ * *shard_ms_max = longest per-shard view/pack time (one per device thread, concurrent);
+ * check != 0 validates every shard like a caller's batch */
+int ahsoka_test_multi_plan(const ahsoka_chain_batch* in, const ahsoka_phase_params* prm,
+                           int32_t n_devices, int32_t* owner_out, int32_t* blocks_out,
+                           double* serial_ms, double* shard_ms_max, int32_t check);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     L = capi.lib()
     for name in declared_symbols():
         assert hasattr(L, name), name
-    assert L.ahsoka_abi_version() == 2
+    assert L.ahsoka_abi_version() == 3
 
 
 def test_default_params_are_the_reference_literals():
@@ -34,6 +34,18 @@ def test_default_params_are_the_reference_literals():
     # src/alignmentstoreadset.cpp:306,158,311,320
     assert (p.ploidy, p.min_mapq, p.min_variants, p.min_overlap) == (2, 93, 2, 1)
     assert (p.switch_cost, p.affine_switch_cost, p.compaction_mode) == (32.0, 8.0, 0)
+    # HaploThreader(ploidy, 32.0, 8.0, false, 0), :320
+    assert (p.symmetry_opt, p.row_limit) == (0, 0)
+
+
+def test_threader_options_other_than_the_reference_literals_are_refused():
+    """symmetryOptimization / rowLimit of :320 are at the boundary; only (false, 0) is implemented"""
+    L = capi.lib()
+    b = capi.synth_batch(**capi.CONFIGS["c1"])
+    h = C.c_void_p()
+    for bad in (dict(symmetry_opt=1), dict(row_limit=5)):
+        prm = capi.default_params(**bad)
+        assert L.ahsoka_batch_upload(b.ptr(), C.byref(prm), C.byref(h)) == capi.E_UNSUPPORTED, bad
 
 
 def test_argument_errors():
@@ -175,3 +187,27 @@ def test_bench_picks_newest_pmc_summary(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.pmc_traffic("c3", 10000) == 12.0
     assert bench.pmc_traffic("c3", 123) is None
+
+
+def test_multi_plan_blocks_for_equal_chains_are_views_and_lpt_for_skewed():
+    """ahsoka_phase_batch_multi's static partition (host only): equal chains -> contiguous blocks,
+    i.e. zero-copy views of the caller's arrays; power-law chains -> LPT.  Every shard validates
+    as a batch of its own, every chain has exactly one owner, blocks are ranges in input order."""
+    import numpy as np
+
+    b = capi.synth_batch(n_chains=240, n_bubbles=12, n_reads=120, seed=77)
+    for nd in (2, 3, 8):
+        owner, blocks, serial_ms, shard_ms = capi.multi_plan(b, nd)
+        assert blocks
+        assert (np.diff(owner) >= 0).all() and set(owner.tolist()) == set(range(nd))
+        cnt = np.bincount(owner, minlength=nd)
+        assert cnt.max() - cnt.min() <= max(2, 240 // nd // 8)
+    sk = capi.synth_batch(n_chains=600, n_bubbles=0, n_reads=0, b_mode=1, mean_span=10.0, seed=0xA450CA05)
+    owner, blocks, _, _ = capi.multi_plan(sk, 4)
+    assert len(owner) == 600 and set(owner.tolist()) <= set(range(4))
+    if not blocks:  # LPT: the shards interleave
+        assert (np.diff(owner) < 0).any()
+    # more devices than chains: empty shards are legal
+    tiny = capi.synth_batch(n_chains=3, n_bubbles=4, n_reads=30, seed=5)
+    owner, _, _, _ = capi.multi_plan(tiny, 8)
+    assert len(owner) == 3

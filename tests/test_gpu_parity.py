@@ -463,6 +463,28 @@ def test_multi_device_entry_equals_single_device():
             np.testing.assert_array_equal(m.stages[k], one.stages[k], err_msg=k)
     o = ob.phase_batch(b, prm, n_threads=16)
     np.testing.assert_array_equal(one.hap_allele, o.hap_allele)
+    # both forms of the partition must have run: contiguous blocks (zero-copy views of the caller's
+    # arrays, offsets re-based) and LPT (packed copies made by the device threads)
+    paths = {capi.multi_plan(b, nd, prm)[1] for nd in (2, 3)}
+    eq = capi.synth_batch(n_chains=36, n_bubbles=14, n_reads=160, seed=4242)       # equal chains: blocks
+    one_eq = capi.phase_batch(eq, prm)
+    for devs in ([0, 0], [0, 0, 0, 0, 0]):
+        paths.add(capi.multi_plan(eq, len(devs), prm)[1])
+        m = capi.phase_batch_multi(eq, devs, prm)
+        for k in ("status", "pos_off", "pos", "hap_allele", "hap_cluster", "n_reads", "n_clusters", "n_iterations"):
+            np.testing.assert_array_equal(getattr(m, k), getattr(one_eq, k), err_msg=k)
+        for k in ("vmat_off", "vfull", "vpart", "fread_off", "fread_name", "fread_cluster", "score_off", "score_q"):
+            np.testing.assert_array_equal(m.stages[k], one_eq.stages[k], err_msg=k)
+    # a few chains of very different size, largest first (the reference's size_sorting): no cut balances them
+    sk = _concat([capi.synth_batch(n_chains=1, n_bubbles=nb, n_reads=nr, seed=900 + nb).arrays()
+                  for nb, nr in ((60, 700), (30, 400), (28, 380), (12, 150), (10, 120), (9, 100), (8, 90))])
+    paths.add(capi.multi_plan(sk, 3, prm)[1])
+    one_sk = capi.phase_batch(sk, prm)
+    m = capi.phase_batch_multi(sk, [0, 0, 0], prm)
+    for k in ("status", "pos_off", "pos", "hap_allele", "hap_cluster", "n_iterations"):
+        np.testing.assert_array_equal(getattr(m, k), getattr(one_sk, k), err_msg=k)
+    np.testing.assert_array_equal(m.stages["score_q"], one_sk.stages["score_q"])
+    assert paths == {True, False}, paths
     # ploidy 4 (genotype array travels with the shards), no stages
     b4 = capi.synth_batch(n_chains=9, n_bubbles=12, n_reads=240, ploidy=4, seed=0xA450CA04)
     p4 = capi.default_params(ploidy=4)

@@ -200,3 +200,53 @@ def test_parse_errors(tmp_path):
     gaf.write_text("r\t1\t0\t1\t+\t>utg000001l\t1\t0\t1\t1\t1\t60\tNM:i:0\tAS:f:0\tdv:f:0\tid:f:0.95\n")
     b = capi.ingest(str(gfa), str(gaf))
     assert b.n_chains == 0  # a single edge forms no bubble
+
+
+def test_allele_path_listing_above_the_bound_is_marked_truncated(tmp_path):
+    """findPathsComplex (src/chainstoreadset.cpp:84-116) lists every path of a superbubble; the
+    ingest stops at 1024 and must SAY so: a layered superbubble of 11 x 2 inner nodes has 2^11
+    paths -> the dump carries a TRUNCATED line after the bubble's 1024 ALLELE lines, a 10-layer one
+    (exactly 1024 paths... listed in full) carries none below the bound (9 layers: 512)."""
+    def layered(layers):
+        names = lambda i: "utg%06dl" % i
+        # one simple bubble first (so the chain has 2 bubbles), then the layered superbubble, whose sink
+        # is the highest node: the reference's DFS starts at the sink and follows its '-' links
+        head, src = (2, 3), 4
+        nid = 5
+        lay = []
+        for _ in range(layers):
+            lay.append((nid, nid + 1)); nid += 2
+        snk = nid
+        n_nodes = snk
+        S = "".join("S\t%s\tA\n" % names(i) for i in range(1, n_nodes + 1))
+        L = []
+        def link(a, b):
+            L.append("L\t%s\t+\t%s\t+\t0M\n" % (names(a), names(b)))
+            L.append("L\t%s\t-\t%s\t-\t0M\n" % (names(b), names(a)))
+        for x in head:
+            link(1, x)
+            link(x, src)
+        for x in lay[0]:
+            link(src, x)
+        for k in range(layers - 1):
+            for x in lay[k]:
+                for y in lay[k + 1]:
+                    link(x, y)
+        for x in lay[-1]:
+            link(x, snk)
+        return S + "".join(L)
+    for layers, expect_cut in ((11, True), (9, False)):
+        gfa = tmp_path / ("l%d.gfa" % layers)
+        gfa.write_text(layered(layers))
+        out = tmp_path / ("l%d.txt" % layers)
+        capi.ingest_dump(str(gfa), "", str(out))
+        lines = open(out).read().split("\n")
+        big = [ln for ln in lines if ln.startswith("BUBBLE ") and int(ln.split()[5]) == 2 * layers]
+        assert len(big) == 1, "the layered part must be ONE bubble"
+        cid, bid = big[0].split()[1:3]
+        n_alleles = sum(1 for ln in lines if ln.startswith("ALLELE %s %s " % (cid, bid)))
+        cut = [ln for ln in lines if ln.startswith("TRUNCATED")]
+        if expect_cut:
+            assert n_alleles == 1024 and cut == ["TRUNCATED %s %s 1024" % (cid, bid)]
+        else:
+            assert n_alleles == 2 ** layers and cut == []

@@ -17,13 +17,6 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 REF_PHASE = os.path.join(ROOT, "oracle", "_ref", "ahsoka_ref_phase")
 
 
-def test_recipe_is_documented_and_unexercised_here():
-    mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
-    assert "_whatshap" in mk and "8f4c0c070d0b5d8e6d2c03e363965d0efb50a960" in mk
-    src = open(os.path.join(ROOT, "oracle", "whatshap_ref_main.cpp")).read()
-    assert '#include "alignmentstoreadset.cpp"' in src and "stand-in" in src
-
-
 @pytest.mark.parametrize("stem", ["c1", "toy", "multi", "sbub"])
 def test_result_text_equals_reference_run(stem, tmp_path):
     if not os.path.exists(REF_PHASE):
