@@ -114,7 +114,7 @@ ABI_SYMBOLS = [
     "ahsoka_batch_free", "ahsoka_batch_result_device", "ahsoka_batch_kernel_times", "ahsoka_batch_bytes", "ahsoka_render_chain",
     "ahsoka_ingest", "ahsoka_ingest_dump", "ahsoka_batch_host_free", "ahsoka_synth_batch", "ahsoka_synth_select", "ahsoka_synth_shapes", "ahsoka_synth_write_text", "ahsoka_synth_truth",
     "ahsoka_test_introsort_u32", "ahsoka_test_introsort_par_u32", "ahsoka_test_detlog",
-    "ahsoka_test_multi_plan",
+    "ahsoka_test_multi_plan", "ahsoka_kernel_revision",
 ]
 
 _lib = None
@@ -134,6 +134,8 @@ def lib() -> C.CDLL:
     L.ahsoka_default_params.argtypes = [C.POINTER(CPhaseParams)]
     L.ahsoka_default_params.restype = None
     L.ahsoka_backend_info.argtypes = [C.c_char_p, C.c_size_t]
+    L.ahsoka_kernel_revision.argtypes = []
+    L.ahsoka_kernel_revision.restype = C.c_char_p
     L.ahsoka_phase_batch.argtypes = [C.POINTER(CChainBatch), C.POINTER(CPhaseParams), C.POINTER(CPhaseResult)]
     L.ahsoka_result_free.argtypes = [C.POINTER(CPhaseResult)]
     L.ahsoka_result_free.restype = None
@@ -193,6 +195,10 @@ def backend_info() -> str:
     buf = C.create_string_buffer(128)
     lib().ahsoka_backend_info(buf, 128)
     return buf.value.decode()
+
+
+def kernel_revision() -> str:
+    return lib().ahsoka_kernel_revision().decode()
 
 
 def _np(ptr, n, dtype):

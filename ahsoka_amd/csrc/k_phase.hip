@@ -577,6 +577,10 @@ __device__ __forceinline__ void tri_seg_wide(const int* __restrict__ Wm, int n, 
 #ifndef AHK_WAVES_PER_SIMD
 #define AHK_WAVES_PER_SIMD 5
 #endif
+#ifndef AHK_INIT_ROWS
+#define AHK_INIT_ROWS 4
+#endif
+constexpr int kInitRows = AHK_INIT_ROWS;  // consecutive rows a wave of S5-init prices together (they share every third-edge gather)
 // IC32: induced costs as 2 x uint32 (IcPair32).  Exact for a chain whose induced costs provably stay
 // below 2^32: they are sums of non-negative terms, and every term of icf(a,b) / icp(a,b) is at most
 // |W[b][x]| where that is finite and |W[a][x]| where it is not (never both infinite on a live edge),
@@ -795,46 +799,68 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
     const int nwp_log = nw <= 8 ? 3 : nw <= 16 ? 4 : 5;
     const int nwp = 1 << nwp_log;
     const int RP = 64 >> nwp_log;  // rows a wave handles at once
-    // Each unordered pair {a,b} is computed once, by the wave of its lower end a
-    // (lanes = the neighbours b > a), and stored for both orientations; the row
-    // maxima are folded in with LDS atomics.  Halving the pairs halves the HBM
-    // lines of the W[w][b] gathers: this phase runs at ~80 % of the achievable
-    // HBM rate (the 190 neighbour rows of a read do not fit any cache share).
+    // Each unordered pair {a,b} is computed once, by the wave of its lower end a (lanes = the
+    // neighbours b > a), and stored for both orientations; the row maxima are folded in with LDS
+    // atomics.  A wave takes kInitRows CONSECUTIVE rows at a time: reads are sorted by first
+    // position, so neighbouring rows have nearly the same neighbours, and over the union of their
+    // neighbour lists every third-edge gather W[w][b] (one row segment of W per w: 3-4 HBM lines)
+    // is made ONCE and priced against all rows of the group -- a non-neighbour w of a row has
+    // weight 0 there and both of its terms vanish, so the union needs no per-row masks.  One row
+    // per wave re-read each chain's 1.4 MB of weights ~30 times (a fifth of the kernel's HBM
+    // traffic, round 2); four rows per group make a quarter of those gathers and drop the
+    // v_readlane of the row weight from three of four terms.
     for (int u = tid; u < n; u += kBlock) { bestF[u] = 0ull; bestP[u] = 0ull; }
     __syncthreads();
     {
-      unsigned short* nbr = listA + (size_t)wv * nmax;   // all neighbours of a, ascending (the role lists are free here)
-      for (int a = wv; a < n; a += 4) {
+      // induced costs of a narrow (IC32) chain are < 2^32 and sums of non-negative terms: 32-bit
+      // unsigned accumulators are exact there
+      using AccT = typename std::conditional<IC32, unsigned int, long long>::type;
+      unsigned short* nbr = listA + (size_t)wv * nmax;   // union of the group's neighbours, ascending (the role lists are free here)
+      for (int a0 = wv * kInitRows; a0 < n; a0 += 4 * kInitRows) {
+        const int R = n - a0 < kInitRows ? n - a0 : kInitRows;
         int deg = 0, dhi = 0;
         for (int w0 = 0; w0 < n; w0 += 64) {
           const int w = w0 + lane;
-          const bool nz = w < n && WM_AT((unsigned)(a * n + w)) != 0;
-          const unsigned long long mk = __ballot(nz);
-
-          const unsigned long long mh = __ballot(nz && w > a);
-          if (nz) nbr[deg + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)w;
-          deg += __popcll(mk);
-          dhi += __popcll(mh);
-          if (lane == 0) {
-            LV_AT((unsigned)(a * nw + (w0 >> 6))) = mk;
-            NZ_AT((unsigned)(a * nw + (w0 >> 6))) = mk;
+          bool nzu = false;
+#pragma unroll
+          for (int r = 0; r < kInitRows; r++) {
+            const bool nz = r < R && w < n && WM_AT((unsigned)((a0 + r) * n + w)) != 0;
+            const unsigned long long mk = __ballot(nz);
+            if (r < R && lane == 0) {
+              LV_AT((unsigned)((a0 + r) * nw + (w0 >> 6))) = mk;
+              NZ_AT((unsigned)((a0 + r) * nw + (w0 >> 6))) = mk;
+            }
+            nzu = nzu || nz;
           }
+          const unsigned long long mu = __ballot(nzu);
+          const unsigned long long mh = __ballot(nzu && w > a0);
+          if (nzu) nbr[deg + __popcll(mu & ((1ull << lane) - 1ull))] = (unsigned short)w;
+          deg += __popcll(mu);
+          dhi += __popcll(mh);
         }
-        // lanes = the neighbours b > a.  The row's own weights W[a][w] are wave-uniform:
-        // 64 of them are fetched with ONE load (lane = neighbour index) and handed out
-        // with v_readlane -- as scalar operands -- instead of 64 uniform loads; padding
-        // neighbours read as weight 0 (both terms vanish), so nothing is predicated.
-        const unsigned short* nhi = nbr + (deg - dhi);  // the neighbours b > a: the tail of the ascending list
+        // lanes = the union's members b > a0 (the tail of the ascending list): a pair (a_r, b) of the
+        // group is this wave's iff b > a_r and W[a_r][b] != 0.  The rows' own weights W[a_r][w] are
+        // wave-uniform: 64 of them per row come with ONE load (lane = list index) and are handed out
+        // with v_readlane; padding entries read as weight 0 (both terms vanish): nothing is predicated.
+        const unsigned short* nhi = nbr + (deg - dhi);
         for (int i0 = 0; i0 < dhi; i0 += 64) {
           const int i = i0 + lane;
           const bool act = i < dhi;
-          const int b = act ? (int)nhi[i] : a;
-          const int wab = WM_AT((unsigned)(a * n + b));  // (a,a) is 0
-          long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
+          const int b = act ? (int)nhi[i] : a0;
+          int wab[kInitRows];
+          AccT f[kInitRows], p[kInitRows];
+#pragma unroll
+          for (int r = 0; r < kInitRows; r++) {
+            wab[r] = r < R ? WM_AT((unsigned)((a0 + r) * n + b)) : 0;  // (a,a) is 0
+            f[r] = (AccT)(wab[r] > 0 ? wab[r] : 0);
+            p[r] = (AccT)(wab[r] < 0 ? -wab[r] : 0);
+          }
           for (int k0 = 0; k0 < deg; k0 += 64) {
             const int kk = k0 + lane;
-            const int nb_l = kk < deg ? (int)nbr[kk] : a;
-            const int wa_l = WM_AT((unsigned)(a * n + nb_l));
+            const int nb_l = kk < deg ? (int)nbr[kk] : a0;
+            int wa_l[kInitRows];
+#pragma unroll
+            for (int r = 0; r < kInitRows; r++) wa_l[r] = (r < R && kk < deg) ? WM_AT((unsigned)((a0 + r) * n + nb_l)) : 0;
             const int cnt = deg - k0 < 64 ? deg - k0 : 64;
             for (int c0 = 0; c0 < cnt; c0 += 8) {
               int wb[8];
@@ -845,23 +871,30 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
               }
 #pragma unroll
               for (int c = 0; c < 8; c++) {
-                const int wa = __builtin_amdgcn_readlane(wa_l, c0 + c);
-                f += icf_term(wa, wb[c]);
-                p += icp_term(wa, wb[c]);
+#pragma unroll
+                for (int r = 0; r < kInitRows; r++) {
+                  const int wa = __builtin_amdgcn_readlane(wa_l[r], c0 + c);
+                  f[r] += (AccT)icf_term(wa, wb[c]);
+                  p[r] += (AccT)icp_term(wa, wb[c]);
+                }
               }
             }
           }
-          if (act) {
-            IcT v;
-            v.f = f;
-            v.p = p;
-            IC_AT((unsigned)(a * n + b)) = v;
-            IC_AT((unsigned)(b * n + a)) = v;
-            const unsigned long long kf = mkkey(f, a, b), kp = mkkey(p, a, b);
-            atomicMax(&bestF[a], kf);
-            atomicMax(&bestP[a], kp);
-            atomicMax(&bestF[b], kf);
-            atomicMax(&bestP[b], kp);
+#pragma unroll
+          for (int r = 0; r < kInitRows; r++) {
+            const int a = a0 + r;
+            if (act && r < R && b > a && wab[r] != 0) {
+              IcT v;
+              v.f = f[r];
+              v.p = p[r];
+              IC_AT((unsigned)(a * n + b)) = v;
+              IC_AT((unsigned)(b * n + a)) = v;
+              const unsigned long long kf = mkkey((long long)f[r], a, b), kp = mkkey((long long)p[r], a, b);
+              atomicMax(&bestF[a], kf);
+              atomicMax(&bestP[a], kp);
+              atomicMax(&bestF[b], kf);
+              atomicMax(&bestP[b], kp);
+            }
           }
         }
       }

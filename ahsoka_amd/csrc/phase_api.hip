@@ -151,6 +151,7 @@ extern "C" void ahsoka_default_params(ahsoka_phase_params* prm) {
 }
 
 extern "C" int ahsoka_abi_version(void) { return AHSOKA_ABI_VERSION; }
+extern "C" const char* ahsoka_kernel_revision(void) { return AHK_KERNEL_REV; }
 
 extern "C" int ahsoka_backend_info(char* buf, size_t buflen) {
   if (!buf || buflen == 0) return AHSOKA_E_ARG;
@@ -535,6 +536,17 @@ static int upload_impl(const ahsoka_chain_batch* in, const ahsoka_phase_params* 
   if (const char* sa = std::getenv("AHSOKA_STOP_AFTER")) h->stop_after = std::atoi(sa);  // diagnostic builds only
 #endif
   if (readset_lds_bytes(h->rl) > h->lds_per_block) return fail(AHSOKA_E_UNSUPPORTED);  // (cannot happen: such chains were flagged)
+#ifdef AHK_DIAG
+  // diagnostic builds only: AHSOKA_CU_STRIDE=k runs the kernels on every k-th CU (a CU-masked stream): tells a
+  // per-CU bound from a chip-wide one (same workgroups per CU, a fraction of the chip)
+  if (const char* cs = std::getenv("AHSOKA_CU_STRIDE")) {
+    const int stride = std::max(1, std::atoi(cs));
+    std::vector<uint32_t> mask((size_t)(h->n_cu + 31) / 32, 0u);
+    for (int cu = 0; cu < h->n_cu; cu += stride) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+    if (hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) return fail(AHSOKA_E_HIP);
+    h->n_cu = (h->n_cu + stride - 1) / stride;
+  } else
+#endif
   if (hipStreamCreate(&h->stream) != hipSuccess) return fail(AHSOKA_E_HIP);
   for (int i = 0; i < 3; i++)
     if (hipEventCreate(&h->ev[i]) != hipSuccess) return fail(AHSOKA_E_HIP);

@@ -3,6 +3,12 @@
 #pragma once
 #include <stdint.h>
 
+// Revision tag of the kernels' memory behaviour.  Bumped with every change of k_phase / k_readset
+// that can move their HBM traffic or time: a committed counter summary (profiles/*_pmc_hbm.json)
+// carries the tag it was taken with, and bench.py reports `roofline.traffic` only from a summary
+// of the SAME revision (never a counter of one kernel version next to a time of another).
+#define AHK_KERNEL_REV "r03.1"
+
 namespace ahk {
 
 // compiled-in device limits (a chain beyond them comes back AHSOKA_ST_UNSUPPORTED)

@@ -213,7 +213,7 @@ def main():
         alg_bytes = m["alg_bytes"]
         kp = m["k_phase_ms"]
         achieved = alg_bytes / (kp * 1e-3) / 1e9
-        traffic = pmc_traffic(args.config, len(sh.owned[0]))
+        traffic, traffic_src = pmc_traffic(args.config, len(sh.owned[0]), capi.kernel_revision())
         stream = stream_copy_gbps(torch, device)
         shape = (f"{cfg['n_bubbles']} bubbles x {cfg['n_reads']} reads/chain" if cfg.get("b_mode", 0) == 0
                  else "power-law bubble counts (1..500), ~40x read depth")
@@ -252,6 +252,8 @@ def main():
                 # the measured traffic (committed PMC summary of this workload) over this run's kernel
                 # time, against the nominal peak and against a streaming copy measured in this job
                 "traffic_rate_GBps": (traffic / (kp * 1e-3) / 1e9) if traffic else None,
+                "traffic_source": traffic_src,
+                "kernel_rev": capi.kernel_revision(),
                 "stream_copy_GBps": stream,
             },
             "phased_bubbles_per_step": m["phased"],
@@ -302,10 +304,11 @@ def stream_copy_gbps(torch, device):
     return 2.0 * n * 4 / (ms * 1e-3) / 1e9
 
 
-def pmc_traffic(config, chains):
+def pmc_traffic(config, chains, kernel_rev):
     """HBM bytes of one k_phase launch from the committed rocprofv3 PMC summary
-    (tools/pmc.sh, separate FETCH_SIZE / WRITE_SIZE passes) of this very workload;
-    None if the summary is for another workload.  (2*FETCH_SIZE + WRITE_SIZE)*1024:
+    (tools/pmc.sh, separate FETCH_SIZE / WRITE_SIZE passes) of this very workload AND this very
+    kernel revision (ahsoka_kernel_revision(): a counter of one kernel version is never put next
+    to a time of another); (None, None) if there is no such summary.  (2*FETCH_SIZE + WRITE_SIZE)*1024:
     the gfx950 half-count of FETCH_SIZE was calibrated on scattered 4- and 16-byte
     reads as well (profiles/r01_fetch_calibration.json): 64 B tallied per request."""
     import glob
@@ -321,9 +324,9 @@ def pmc_traffic(config, chains):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("config") == config and d.get("chains") == chains:
-            return d["kernels"]["k_phase"]["hbm_bytes_fetch_x2"]
-    return None
+        if d.get("config") == config and d.get("chains") == chains and d.get("kernel_rev") == kernel_rev:
+            return d["kernels"]["k_phase"]["hbm_bytes_fetch_x2"], os.path.relpath(f, ROOT)
+    return None, None
 
 
 def cpu_baseline(cfg, prm, n_sample):

@@ -179,6 +179,9 @@ void ahsoka_default_params(ahsoka_phase_params* prm);
 /* "hip:<gfx name>:<CUs>" or an error string; never fails hard. */
 int ahsoka_backend_info(char* buf, size_t buflen);
 int ahsoka_abi_version(void);
+/* revision tag of the device kernels (static string): measurement bookkeeping -- a counter
+ * summary under profiles/ is only ever paired with timings of the same revision */
+const char* ahsoka_kernel_revision(void);
 
 /*
  * THE hot path.  Replaces one call of alignmentsToReadset

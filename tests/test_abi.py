@@ -175,18 +175,23 @@ def test_algorithmic_bytes_formula():
 
 
 def test_bench_picks_newest_pmc_summary(tmp_path, monkeypatch):
-    """profiles/r<round>_v<version>_pmc_hbm.json are ordered numerically (v12 after v9)"""
+    """profiles/r<round>_v<version>_pmc_hbm.json are ordered numerically (v12 after v9), and a summary is
+    only ever used for the kernel revision it was taken with (no counter of one kernel version next to
+    a time of another)"""
     import json
     import bench
 
     prof = tmp_path / "profiles"
     prof.mkdir()
-    for tag, val in (("r01_v9", 9.0), ("r01_v12", 12.0), ("r01_v3", 3.0)):
+    for tag, val, rev in (("r01_v9", 9.0, "A"), ("r01_v12", 12.0, "A"), ("r01_v3", 3.0, "A"), ("r01_v13", 13.0, "B")):
         (prof / f"{tag}_pmc_hbm.json").write_text(json.dumps(
-            {"config": "c3", "chains": 10000, "kernels": {"k_phase": {"hbm_bytes_fetch_x2": val}}}))
+            {"config": "c3", "chains": 10000, "kernel_rev": rev, "kernels": {"k_phase": {"hbm_bytes_fetch_x2": val}}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    assert bench.pmc_traffic("c3", 10000) == 12.0
-    assert bench.pmc_traffic("c3", 123) is None
+    assert bench.pmc_traffic("c3", 10000, "A") == (12.0, os.path.join("profiles", "r01_v12_pmc_hbm.json"))
+    assert bench.pmc_traffic("c3", 10000, "B")[0] == 13.0
+    assert bench.pmc_traffic("c3", 10000, "C") == (None, None)   # another kernel revision: no figure
+    assert bench.pmc_traffic("c3", 123, "A") == (None, None)
+    assert capi.kernel_revision().startswith("r")
 
 
 def test_multi_plan_blocks_for_equal_chains_are_views_and_lpt_for_skewed():

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """gpurun_out/<tag>_pmc.txt (tools/pmc.sh output) -> profiles/<tag>_pmc_hbm.json"""
-import json, sys
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ahsoka_amd import capi
 tag, config, chains = sys.argv[1], sys.argv[2], int(sys.argv[3])
+# the kernel revision the counters were taken with: argument 4, else the library built here (run this
+# right after the profile, before the kernels change)
+rev = sys.argv[4] if len(sys.argv) > 4 else capi.kernel_revision()
 k = {}
 for line in open(f"gpurun_out/{tag}_pmc.txt"):
     p = line.split()
@@ -17,7 +22,7 @@ for v in k.values():
     v["hbm_bytes_fetch_x2"] = (2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024
 out = {
     "what": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh), python3 bench.py --chains {chains} --steps 1 --warmup 0 (BASELINE configs[2], one launch of each kernel)",
-    "config": config, "chains": chains,
+    "config": config, "chains": chains, "kernel_rev": rev,
     "note": "hbm_bytes_fetch_x2 = (2*FETCH_SIZE + WRITE_SIZE)*1024 is the calibrated reading: FETCH_SIZE tallies 64 B per 128-B request on gfx950, for scattered 4/16-B reads as for wide streams (profiles/r01_fetch_calibration.json)",
     "kernels": k,
 }
