@@ -127,24 +127,32 @@ __device__ __forceinline__ int icp_term(int p, int q) {
 }
 #endif
 // Packed key of an edge (a,b), a < b, with induced cost val >= 0:
-//   (val+1) << 23 | stale << 22 | (2047-a) << 11 | (2047-b)
+//   (val+1) << 25 | stale << 24 | (4095-a) << 12 | (4095-b)
 // One unsigned 64-bit max picks the largest value and, among equal values, the
 // lexicographically smallest pair -- the heuristic's global tie rule.  Within one
 // row that is also "smallest other end", so the per-row maxima are kept in this
 // very form and the argmax is a plain max over them.  The stale bit marks a row
 // maximum that is only an upper bound (its edge went down or died): among equal
 // values a stale key wins the max, which is exactly "some stale row ties the
-// maximum -> rescan before deciding".  val+1 <= 2047 * 2^30 < 2^41 (weights are
-// clamped to 2^30, n <= 2048).  0 = no live edge.
-constexpr unsigned long long kStale = 1ull << 22;
-constexpr unsigned long long kPairMask = (1ull << 22) - 1ull;
+// maximum -> rescan before deciding".  The ends are 12-bit fields (n <= 4096 = kMaxReads), which
+// leaves 39 bits for val+1: exact for every narrow (32-bit induced cost) chain; the wide instance
+// checks its chain's bound 2 * max row sum of |W| < 2^39 - 1 once, after S4b, and reports a chain
+// beyond it AHSOKA_ST_UNSUPPORTED (weights are clamped to 2^30: more than 256 neighbours at the clamp).
+// 0 = no live edge.
+constexpr int kKeyEndBits = 12;
+constexpr unsigned int kKeyEndMax = (1u << kKeyEndBits) - 1u;            // 4095
+constexpr int kKeyValShift = 2 * kKeyEndBits + 1;                         // 25
+constexpr unsigned long long kStale = 1ull << (2 * kKeyEndBits);          // bit 24
+constexpr unsigned long long kPairMask = (1ull << (2 * kKeyEndBits)) - 1ull;
+constexpr long long kKeyValMax = (1ll << (64 - kKeyValShift)) - 2;       // largest val a key can carry
+static_assert(kMaxReads <= (1 << kKeyEndBits), "packed edge keys hold 12-bit read indices");
 __device__ __forceinline__ unsigned long long mkkey(long long val, int r, int c) {
   const unsigned int a = r < c ? r : c, b = r < c ? c : r;
-  return ((unsigned long long)(val + 1) << 23) | (unsigned long long)(((2047u - a) << 11) | (2047u - b));
+  return ((unsigned long long)(val + 1) << kKeyValShift) | (unsigned long long)(((kKeyEndMax - a) << kKeyEndBits) | (kKeyEndMax - b));
 }
-__device__ __forceinline__ long long key_val(unsigned long long k) { return (long long)(k >> 23) - 1; }
-__device__ __forceinline__ int key_a(unsigned long long k) { return 2047 - (int)((k >> 11) & 2047ull); }
-__device__ __forceinline__ int key_b(unsigned long long k) { return 2047 - (int)(k & 2047ull); }
+__device__ __forceinline__ long long key_val(unsigned long long k) { return (long long)(k >> kKeyValShift) - 1; }
+__device__ __forceinline__ int key_a(unsigned long long k) { return (int)kKeyEndMax - (int)((k >> kKeyEndBits) & (unsigned long long)kKeyEndMax); }
+__device__ __forceinline__ int key_b(unsigned long long k) { return (int)kKeyEndMax - (int)(k & (unsigned long long)kKeyEndMax); }
 // the other end of the edge in key k, seen from its end r
 __device__ __forceinline__ int key_other(unsigned long long k, int r) {
   const int a = key_a(k), b = key_b(k);
@@ -399,6 +407,17 @@ __device__ __forceinline__ void rescan_list(const unsigned short* dlist, int nd,
   }
 }
 
+// S4a sort key of a scored pair: (Hamming rate d/o as floor(d * 2^20 / o), overlap o) -- the exact order by
+// rate, ties by overlap.  o <= 4095 covered positions (kMaxBubbles) take 12 bits; the rate of a pair that
+// differs everywhere (d == o: 2^20, the only value above 2^20 - 2^20/o) is stored as 2^20 - 2, which keeps
+// its place in the order, still gives d back as ceil(rate * o / 2^20), and leaves 0xFFFFFFFF free as the
+// "not scored" mark.  (oracle.cpp: the same function)
+__device__ __forceinline__ unsigned int rate_key(unsigned int d, unsigned int o) {
+  unsigned int rate = (d << 20) / o;
+  if (rate > (1u << 20) - 2u) rate = (1u << 20) - 2u;
+  return (rate << 12) | o;
+}
+
 struct GreaterCnt {  // cmp() of the reference, :699-701: coverage descending
   __host__ __device__ bool operator()(unsigned int x, unsigned int y) const { return (x >> 16) > (y >> 16); }
 };
@@ -619,12 +638,14 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
   unsigned short* rowbuf = listFb + nmax;                 // [4][nmax] as u16 = the first 2*nmax entries of the candidate-edge list (absent if !lds.items_lds)
   unsigned short* dlist = rowbuf + (lds.items_lds ? 4 * (size_t)nmax : 0);  // [nmax] rows whose maximum must be rescanned
   unsigned int* multiw = (unsigned int*)(dlist + nmax);   // [nmax/32] bit per read: its clique has > 1 member
-  unsigned long long* rmask = (unsigned long long*)(multiw + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][32] role masks per 64-column word
-  unsigned long long* rolenz = rmask + 4 * 32;             // [4][32] OR of the members' nz-rows
-  unsigned char* role = (unsigned char*)(rolenz + 4 * 32);  // [nmax]
+  // words of a bitmap row the class can have: 32 (n <= 2048) or 64 -- sizes the per-word role tables
+  const int RW = lds.nmax > 2048 ? 64 : 32;
+  unsigned long long* rmask = (unsigned long long*)(multiw + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][RW] role masks per 64-column word
+  unsigned long long* rolenz = rmask + 4 * RW;             // [4][RW] OR of the members' nz-rows
+  unsigned char* role = (unsigned char*)(rolenz + 4 * RW);  // [nmax]
   int* wrow = (int*)(role + nmax);                         // [nmax] weights of a single read's row (see "staged row")
   __shared__ int s_chain, s_cnt[4], s_nd, s_items, s_nh, s_nslow;
-  __shared__ unsigned short s_pref[4][32];
+  __shared__ unsigned short s_pref[4][64];
 #ifdef AHK_TIMING
   __shared__ int s_chg;
 #endif
@@ -678,7 +699,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
             int o, d;
             pair_overlap(cx, i, j, &o, &d);
             if (o >= db.min_overlap && o > 0) {
-              key = ((((unsigned)d << 20) / (unsigned)o) << 10) | (unsigned)o;
+              key = rate_key((unsigned)d, (unsigned)o);
               cnt++;
               dall += d;
               oall += o;
@@ -694,7 +715,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
           int msel = cnt / ploidy;
           if (msel == 0) msel = 1;
           // smallest key T with #(key <= T) >= msel
-          unsigned int lo = 0, hi = 0x7FFFFFFFu;
+          unsigned int lo = 0, hi = 0xFFFFFFFEu;
           while (lo < hi) {
             const unsigned int mid = lo + ((hi - lo) >> 1);
             int cle = 0;
@@ -709,7 +730,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
           for (int j = lane; j < n; j += 64) {
             const unsigned int key = keybuf[j];
             if (key < T) {
-              const unsigned int o = key & 1023u, rate = key >> 10;
+              const unsigned int o = key & 4095u, rate = key >> 12;
               const unsigned long long dd = ((unsigned long long)rate * o + ((1u << 20) - 1)) >> 20;
               cl_lt++;
               ds += (long long)dd;
@@ -719,7 +740,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
           cl_lt = wave_sum_i(cl_lt);
           ds = wave_sum_ll(ds);
           os = wave_sum_ll(os);
-          const unsigned int oT = T & 1023u, rT = T >> 10;
+          const unsigned int oT = T & 4095u, rT = T >> 12;
           const long long dT = (long long)(((unsigned long long)rT * oT + ((1u << 20) - 1)) >> 20);
           ds += (long long)(msel - cl_lt) * dT;
           os += (long long)(msel - cl_lt) * (long long)oT;
@@ -762,24 +783,32 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         if (m.dump0 >= 0) db.score_dump[m.dump0 + (size_t)i * n + j] = q;
         srow += q < 0 ? -(long long)q : (long long)q;
       }
-      if (IC32) {
-        srow = wave_sum_i64(srow);
-        smax = srow > smax ? srow : smax;
-      }
+      srow = wave_sum_i64(srow);
+      smax = srow > smax ? srow : smax;
     }
-    if (IC32 && lane == 0) s_rk[wv] = (unsigned long long)smax;
+    if (lane == 0) s_rk[wv] = (unsigned long long)smax;
     for (int u = tid; u < n; u += kBlock) {
       cl[u] = (unsigned short)u;
       role[u] = ROLE_NONE;
     }
     __syncthreads();
-    if (IC32) {
+    {
       // every induced cost of this chain is at most S(a) + S(b) <= 2 * max row sum: below 2^32, or the chain goes to
-      // the wide instance (uniform: every wave reads the same four values)
+      // the wide instance (uniform: every wave reads the same four values); the wide instance in turn needs the
+      // value to fit the 39-bit field of the packed edge keys
       unsigned long long sm = s_rk[0];
       for (int k = 1; k < 4; k++) sm = s_rk[k] > sm ? s_rk[k] : sm;
-      if (2ull * sm >= (1ull << 32)) {
-        if (tid == 0) deferred[atomicAdd(ndeferred, 1)] = c;
+      if (IC32) {
+        if (2ull * sm >= (1ull << 32)) {
+          if (tid == 0) deferred[atomicAdd(ndeferred, 1)] = c;
+          continue;
+        }
+      } else if (2ull * sm > (unsigned long long)kKeyValMax) {
+        if (tid == 0) {
+          db.status[c] = AHSOKA_ST_UNSUPPORTED;
+          db.nclusters[c] = 0;
+          db.niter[c] = 0;
+        }
         continue;
       }
     }
@@ -796,7 +825,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
     // iff its bit is set, and IC holds garbage for dead pairs.
     const int nw = (n + 63) >> 6;
     // words per row rounded up to a power of two (>= 8): lane layout of the row passes
-    const int nwp_log = nw <= 8 ? 3 : nw <= 16 ? 4 : 5;
+    const int nwp_log = nw <= 8 ? 3 : nw <= 16 ? 4 : nw <= 32 ? 5 : 6;
     const int nwp = 1 << nwp_log;
     const int RP = 64 >> nwp_log;  // rows a wave handles at once
     // Each unordered pair {a,b} is computed once, by the wave of its lower end a (lanes = the
@@ -970,7 +999,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         // collect the stale rows whose bound ties a maximum, rescan them exactly
         for (int u = tid; u < n; u += kBlock) {
           const unsigned long long k1 = bestF[u], k2 = bestP[u];
-          if (((k1 & kStale) && (k1 >> 23) == (gF >> 23)) || ((k2 & kStale) && (k2 >> 23) == (gP >> 23)))
+          if (((k1 & kStale) && (k1 >> kKeyValShift) == (gF >> kKeyValShift)) || ((k2 & kStale) && (k2 >> kKeyValShift) == (gP >> kKeyValShift)))
             dlist[atomicAdd(&s_nd, 1)] = (unsigned short)u;
         }
         __syncthreads();
@@ -1131,10 +1160,10 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         const unsigned long long m3 = __ballot(r == ROLE_FA), m4 = __ballot(r == ROLE_FB);
         const int k = (z0 >> 6) + wv;
         if (lane == 0 && k < nw) {
-          rmask[0 * 32 + k] = m1;
-          rmask[1 * 32 + k] = m2;
-          rmask[2 * 32 + k] = m3;
-          rmask[3 * 32 + k] = m4;
+          rmask[0 * RW + k] = m1;
+          rmask[1 * RW + k] = m2;
+          rmask[2 * RW + k] = m3;
+          rmask[3 * RW + k] = m4;
         }
       }
       __syncthreads();
@@ -1143,10 +1172,10 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
       // (consecutive list entries are neighbouring columns: the row accesses W[x][w] over a
       // list touch few lines, and the heavy-edge pass relies on the order)
       {
-        const unsigned long long mw = lane < nw ? rmask[wv * 32 + lane] : 0ull;
+        const unsigned long long mw = lane < nw ? rmask[wv * RW + lane] : 0ull;
         const int pc = __popcll(mw);
         const int incl = wave_scan_i(pc);
-        if (lane < 32) s_pref[wv][lane] = (unsigned short)(incl - pc);
+        s_pref[wv][lane] = (unsigned short)(incl - pc);
         if (lane == 63) s_cnt[wv] = incl;
       }
       __syncthreads();
@@ -1154,7 +1183,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         const int r = role[z];
         if (r == ROLE_NONE) continue;
         const int k = z >> 6;
-        const int slot = (int)s_pref[r - 1][k] + __popcll(rmask[(r - 1) * 32 + k] & ((1ull << (z & 63)) - 1ull));
+        const int slot = (int)s_pref[r - 1][k] + __popcll(rmask[(r - 1) * RW + k] & ((1ull << (z & 63)) - 1ull));
         unsigned short* Lz = r == ROLE_A ? listA : r == ROLE_B ? listB : r == ROLE_FA ? listFa : listFb;
         Lz[slot] = (unsigned short)z;
       }
@@ -1191,7 +1220,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
             for (int c = 0; c < 8; c++) acc |= t[c];
           }
         }
-        if (lane < 32) rolenz[wv * 32 + lane] = acc;
+        if (lane < RW) rolenz[wv * RW + lane] = acc;
       }
       __syncthreads();
       AHK_T(2);
@@ -1219,8 +1248,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         // this lane's word of every role mask / neighbour mask: read from LDS once
         unsigned long long mA = 0ull, mB = 0ull, mFa = 0ull, mFb = 0ull, oA = 0ull, oB = 0ull, oFa = 0ull, oFb = 0ull;
         if (wordok) {
-          mA = rmask[kw]; mB = rmask[32 + kw]; mFa = rmask[64 + kw]; mFb = rmask[96 + kw];
-          oA = rolenz[kw]; oB = rolenz[32 + kw]; oFa = rolenz[64 + kw]; oFb = rolenz[96 + kw];
+          mA = rmask[kw]; mB = rmask[RW + kw]; mFa = rmask[2 * RW + kw]; mFb = rmask[3 * RW + kw];
+          oA = rolenz[kw]; oB = rolenz[RW + kw]; oFa = rolenz[2 * RW + kw]; oFb = rolenz[3 * RW + kw];
         }
         const unsigned long long Tm = mA | mB | mFa | mFb;
         const unsigned long long segmask = (nwp == 64 ? ~0ull : ((1ull << nwp) - 1ull)) << (slot << nwp_log);
@@ -2328,7 +2357,7 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   b += (size_t)l.nmax * 2 * 5;             // cl + 4 lists
   b += (size_t)l.nmax * 2 * (l.items_lds ? 5 : 1);  // rowbuf[4] (the LDS part of the candidate-edge list), dlist
   b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4;  // multiw (padded to 8 bytes)
-  b += 2 * 4 * 32 * 8;                                   // rmask, rolenz
+  b += (size_t)2 * 4 * (l.nmax > 2048 ? 64 : 32) * 8;    // rmask, rolenz
   b += (size_t)l.nmax;                     // role
   if (l.stage_row) b += (size_t)l.nmax * 4;  // wrow
   {  // the threading DP re-uses the region: tuple-code map (u16) + one marginal table (u64 + u32)

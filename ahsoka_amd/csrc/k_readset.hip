@@ -34,7 +34,7 @@ namespace ahk {
 // std::sort): every partition is two ballot sweeps (positions of the elements not less / not
 // greater than the pivot), a parallel count of the swaps, the swaps themselves and a closed
 // form of the cut; the final insertion sort is a stable rank inside every leaf.  The array and
-// the scratch arrays live in LDS; call with the 64 lanes of one wave, n <= 2048.
+// the scratch arrays live in LDS; call with the 64 lanes of one wave, n <= 65535.
 //   a[n], posL[n], posR[n] (u16), cutbit[(n+31)/32] (u32), tmp[n]
 __device__ __forceinline__ int wave_sum_small(int v) {
 #pragma unroll
@@ -200,6 +200,16 @@ __device__ bool multiset_includes(const int* __restrict__ path, long long pb, lo
   return true;
 }
 
+// bytes of the LDS region that k_readset uses first for the per-lane node windows and then for the
+// per-read arrays and the sort's scratch
+__host__ __device__ inline size_t readset_region_bytes(const ReadsetLds& l) {
+  const size_t capN = (size_t)(l.maxG < kMaxReads ? l.maxG : kMaxReads);
+  const size_t win = (size_t)l.wordsN * kBlock * 8;
+  const size_t per_read = capN * 4 * 3 + ((capN / 32 + 2 + 1) & ~(size_t)1) * 4 + capN * 2 * 6;
+  const size_t r = win > per_read ? win : per_read;
+  return (r + 15) & ~(size_t)15;
+}
+
 __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds lds, const int* __restrict__ list) {
   extern __shared__ __align__(16) unsigned long long smem[];
   const int c = list[blockIdx.x];
@@ -207,21 +217,30 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
   const int tid = threadIdx.x;
   const int B = m.B, R = m.R, G = m.G;
 
-  unsigned long long* bits = smem;                                   // [wordsN][kBlock]
-  unsigned int* tba = (unsigned int*)(bits + (size_t)lds.wordsN * kBlock);  // [32]
-  unsigned int* firsts = tba + 32;
-  unsigned int* lasts = firsts + 32;
-  unsigned int* posm = lasts + 32;
-  unsigned int* keys = posm + 32;          // [maxG]
-  unsigned int* srt = keys + lds.maxG;     // [maxG]
-  unsigned short* kname = (unsigned short*)(srt + lds.maxG);  // [maxG]
-  unsigned short* insname = kname + lds.maxG;                 // [maxG]
-  unsigned short* kfirst = insname + lds.maxG;                // [maxG]
-  unsigned short* insfirst = kfirst + lds.maxG;               // [maxG]
-  unsigned short* cidx = insfirst + lds.maxG;                 // [maxB+1]
+  // LDS: the per-lane node windows of phase A and the per-read arrays of the later phases share one
+  // region (the windows are dead once the match matrices are in HBM); the position masks follow
+  const int capN = lds.maxG < kMaxReads ? lds.maxG : kMaxReads;  // reads that can reach the final readset
+  const int PW = (lds.maxB + 32) >> 5;                            // u32 words of a position mask
+  unsigned long long* bits = smem;                                   // [wordsN][kBlock]   (phase A)
+  unsigned int* keys = (unsigned int*)smem;                          // [capN]             (phase C on)
+  unsigned int* srt = keys + capN;                                   // [capN]
+  unsigned int* stmp = srt + capN;                                   // [capN]   sort scratch
+  unsigned int* cutbit = stmp + capN;                                // [capN/32 + 2]
+  unsigned short* kname = (unsigned short*)(cutbit + ((capN / 32 + 2 + 1) & ~1));  // [capN]
+  unsigned short* insname = kname + capN;
+  unsigned short* kfirst = insname + capN;
+  unsigned short* insfirst = kfirst + capN;
+  unsigned short* posL = insfirst + capN;                            // [capN]   sort scratch
+  unsigned short* posR = posL + capN;
+  unsigned int* tba = (unsigned int*)((char*)smem + readset_region_bytes(lds));  // [PW]
+  unsigned int* firsts = tba + PW;
+  unsigned int* lasts = firsts + PW;
+  unsigned int* posm = lasts + PW;
+  unsigned short* cidx = (unsigned short*)(posm + PW);               // [maxB+1]
   __shared__ int s_maxpos, s_any, s_n, s_P;
+  __shared__ int s_stk[3 * 64];
 
-  if (tid < 32) { tba[tid] = 0; firsts[tid] = 0; lasts[tid] = 0; posm[tid] = 0; }
+  for (int w = tid; w < PW; w += kBlock) { tba[w] = 0; firsts[w] = 0; lasts[w] = 0; posm[w] = 0; }
   if (tid == 0) { s_maxpos = -1; s_any = 0; s_n = 0; s_P = 0; }
   __syncthreads();
 
@@ -240,13 +259,34 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
   const int wordsN = (m.N + 63) >> 6;
 
   // ---- phase A: per alignment, first fully / partially matching allele -----
+  // The lane's node bitset is a WINDOW of WW words starting at the word of the alignment's smallest
+  // chain node: an alignment touches a short stretch of the chain, whatever the chain's length
+  // (kMaxNodes = 8192 nodes would be 128 words per lane otherwise).  Exact for any alignment: a
+  // node below the window is not on the read; a node above it is looked up in the read's node
+  // list (only alignments that span more than WW*64 node indices ever take that branch).
+  const int WW = wordsN < lds.wordsN ? wordsN : lds.wordsN;
   for (int r = tid; r < R; r += kBlock) {
-    for (int w = 0; w < wordsN; w++) bits[(size_t)w * kBlock + tid] = 0ull;
     const long long e0 = db.rnode_off[m.r0 + r], e1 = db.rnode_off[m.r0 + r + 1];
+    int mn = 0x7fffffff, mx = -1;
     for (long long e = e0; e < e1; e++) {
-      int nd = db.rnode[e];
-      if (nd >= 0) bits[(size_t)(nd >> 6) * kBlock + tid] |= 1ull << (nd & 63);
+      const int nd = db.rnode[e];
+      if (nd >= 0) { mn = nd < mn ? nd : mn; mx = nd > mx ? nd : mx; }
     }
+    const int w0 = mx < 0 ? 0 : (mn >> 6);
+    const bool wide = mx >= 0 && (mx >> 6) - w0 >= WW;
+    for (int w = 0; w < WW; w++) bits[(size_t)w * kBlock + tid] = 0ull;
+    for (long long e = e0; e < e1; e++) {
+      const int nd = db.rnode[e];
+      if (nd >= 0 && (nd >> 6) - w0 < WW) bits[(size_t)((nd >> 6) - w0) * kBlock + tid] |= 1ull << (nd & 63);
+    }
+    auto has = [&](int nd) -> bool {
+      const int wi = (nd >> 6) - w0;
+      if (wi >= 0 && wi < WW) return (bits[(size_t)wi * kBlock + tid] >> (nd & 63)) & 1ull;
+      if (!wide || wi < 0) return false;
+      for (long long e = e0; e < e1; e++)
+        if (db.rnode[e] == nd) return true;
+      return false;
+    };
     for (int k = 0; k < B; k++) {
       int vf = -1, vp = -1;
       const long long a0 = aoff[k], a1 = aoff[k + 1];
@@ -260,18 +300,11 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
           continue;
         }
         bool inner = true;
-        for (long long e = p0 + 1; e < p1 - 1; e++) {
-          int nd = db.apath_node[e];
-          inner = inner && ((bits[(size_t)(nd >> 6) * kBlock + tid] >> (nd & 63)) & 1ull);
-        }
+        for (long long e = p0 + 1; e < p1 - 1; e++) inner = inner && has(db.apath_node[e]);
         bool full = inner;
         if (p1 > p0) {
-          int nd = db.apath_node[p0];
-          full = full && ((bits[(size_t)(nd >> 6) * kBlock + tid] >> (nd & 63)) & 1ull);
-          if (p1 - p0 > 1) {
-            nd = db.apath_node[p1 - 1];
-            full = full && ((bits[(size_t)(nd >> 6) * kBlock + tid] >> (nd & 63)) & 1ull);
-          }
+          full = full && has(db.apath_node[p0]);
+          if (p1 - p0 > 1) full = full && has(db.apath_node[p1 - 1]);
         }
         if (vp < 0 && inner) vp = (int)(a - a0);
         if (vf < 0 && full) vf = (int)(a - a0);
@@ -280,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
       vpart[(long long)k * R + r] = (signed char)vp;
     }
   }
-  __syncthreads();
+  __syncthreads();  // (from here on the window region holds the per-read arrays)
 
   const long long* name_off = db.name_off + m.name0;
   const int* name_aln = db.name_aln + m.r0;
@@ -318,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
   if (tid == 0) {
     // boundaries = {el, el+1 : el in lasts \ firsts}; to_be_added = [0,maxpos) U boundaries
     unsigned int carry = 0;
-    for (int w = 0; w < 32; w++) {
+    for (int w = 0; w < PW; w++) {
       unsigned int bd = lasts[w] & ~firsts[w];
       unsigned int t = bd | (bd << 1) | carry;
       carry = bd >> 31;
@@ -349,9 +382,11 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
     if (nvar >= db.min_variants && mapq >= db.min_mapq) {
       int slot = atomicAdd(&s_n, 1);
       // creation order of the Read objects in partial_readset: (position, allele, alignment)
-      keys[slot] = ((unsigned)first << 21) | ((unsigned)afirst << 17) | (unsigned)rcre;
-      kname[slot] = (unsigned short)g;
-      kfirst[slot] = (unsigned short)first;
+      if (slot < capN) keys[slot] = ((unsigned)first << 20) | ((unsigned)afirst << 16) | (unsigned)rcre;  // (12-bit position, 4-bit allele, 16-bit alignment)
+      if (slot < capN) {
+        kname[slot] = (unsigned short)g;
+        kfirst[slot] = (unsigned short)first;
+      }
       for (int k = first; k < B; k++) {
         if (!tba_test(tba, k)) continue;
         int cr;
@@ -376,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
     unsigned int ki = keys[i];
     int rank = 0;
     for (int j = 0; j < n; j++) rank += (keys[j] < ki) ? 1 : 0;
-    srt[rank] = ((ki >> 21) << 16) | (unsigned)rank;
+    srt[rank] = ((ki >> 20) << 16) | (unsigned)rank;
     insname[rank] = kname[i];
     insfirst[rank] = kfirst[i];
   }
@@ -392,7 +427,9 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
     s_P = P;
   }
   __syncthreads();
-  if (tid == 0) gnu_sort(srt, n, LessHi16());  // ReadSet::sort(): std::sort on firstPosition
+  // ReadSet::sort(): std::sort on firstPosition, in the rank-based form one wavefront can run
+  // (gnusort.h; the same routine k_sortperm uses)
+  if (tid < 64) wave_sort_hi16(srt, n, tid, posL, posR, cutbit, stmp, s_stk);
   __syncthreads();
 
   // ---- phase E: compact variant bit-planes of the final reads --------------
@@ -441,10 +478,8 @@ __global__ __launch_bounds__(kBlock) void k_readset(DeviceBatch db, ReadsetLds l
 }
 
 size_t readset_lds_bytes(const ReadsetLds& l) {
-  size_t b = (size_t)l.wordsN * kBlock * 8;   // bitsets
-  b += 4 * 32 * 4;                            // tba, firsts, lasts, posm
-  b += (size_t)l.maxG * 4 * 2;                // keys, srt
-  b += (size_t)l.maxG * 2 * 4;                // kname, insname, kfirst, insfirst
+  size_t b = readset_region_bytes(l);
+  b += (size_t)4 * ((l.maxB + 32) >> 5) * 4;  // tba, firsts, lasts, posm
   b += (size_t)(l.maxB + 2) * 2;              // cidx
   return (b + 15) & ~(size_t)15;
 }
@@ -595,33 +630,41 @@ __device__ __forceinline__ void match4(const MatchCtx& mc, const AlnBits (&ab)[4
   }
 }
 
-__global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, ReadsetLds2 lds, const int* __restrict__ list) {
+__global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, const int* __restrict__ list) {
   extern __shared__ __align__(16) unsigned long long smem[];
   const int c = list[blockIdx.x];
   const ChainMeta m = db.meta[c];
   const int tid = threadIdx.x;
   const int B = m.B, R = m.R, G = m.G;
 
+  // the LDS arrays are laid out from THIS chain's sizes (readset_lds2_bytes of the same sizes is what
+  // the host checked against the budget; a launch asks for the largest need among its chains)
+  const int wordsN = (m.N + 63) >> 6;
+  const long long a_base = db.allele_off[m.b0];
+  const int SA = (int)(db.allele_off[m.b0 + B] - a_base);
+  const int Gs = G > 0 ? G : 1, Bs = B > 0 ? B : 1;
+  const int PW = (Bs + 32) >> 5;                                        // u32 words of a position mask
+  const int capN = Gs;                                                  // (slots of the per-read arrays)
   unsigned long long* bits = smem;                                     // [wordsN][R]
-  unsigned long long* mfull = bits + (size_t)lds.maxBitWords;          // [SA][wordsN]
-  unsigned long long* minner = mfull + (size_t)lds.maxMaskWords;       // [SA][wordsN]
-  unsigned int* roff = (unsigned int*)(minner + (size_t)lds.maxMaskWords);  // [maxR + 1]
-  unsigned int* tba = roff + ((lds.maxR + 2) & ~1);                     // [32]
-  unsigned int* firsts = tba + 32;
-  unsigned int* lasts = firsts + 32;
-  unsigned int* posm = lasts + 32;
-  unsigned int* keys = posm + 32;          // [maxG]
-  unsigned int* srt = keys + lds.maxG;     // [maxG]
-  unsigned short* kname = (unsigned short*)(srt + lds.maxG);  // [maxG]
-  unsigned short* insname = kname + lds.maxG;                 // [maxG]
-  unsigned short* kfirst = insname + lds.maxG;                // [maxG]
-  unsigned short* insfirst = kfirst + lds.maxG;               // [maxG]
-  unsigned short* cidx = insfirst + lds.maxG;                 // [maxB+1]
-  unsigned short* ahead = cidx + ((lds.maxB + 2) & ~1);       // [maxB+1]
-  unsigned char* adup = (unsigned char*)(ahead + ((lds.maxB + 2) & ~1));  // [maxSA]
+  unsigned long long* mfull = bits + (size_t)wordsN * R;               // [SA][wordsN]
+  unsigned long long* minner = mfull + (size_t)wordsN * SA;            // [SA][wordsN]
+  unsigned int* roff = (unsigned int*)(minner + (size_t)wordsN * SA);  // [R + 1]
+  unsigned int* tba = roff + ((R + 2) & ~1);                            // [PW]
+  unsigned int* firsts = tba + PW;
+  unsigned int* lasts = firsts + PW;
+  unsigned int* posm = lasts + PW;
+  unsigned int* keys = posm + PW;          // [G]
+  unsigned int* srt = keys + Gs;           // [G]
+  unsigned short* kname = (unsigned short*)(srt + Gs);  // [G]
+  unsigned short* insname = kname + Gs;                 // [G]
+  unsigned short* kfirst = insname + Gs;                // [G]
+  unsigned short* insfirst = kfirst + Gs;               // [G]
+  unsigned short* cidx = insfirst + Gs;                 // [B+1]
+  unsigned short* ahead = cidx + ((Bs + 2) & ~1);       // [B+1]
+  unsigned char* adup = (unsigned char*)(ahead + ((Bs + 2) & ~1));  // [SA]
   __shared__ int s_maxpos, s_any, s_n, s_P, s_anydup;
 
-  if (tid < 32) { tba[tid] = 0; firsts[tid] = 0; lasts[tid] = 0; posm[tid] = 0; }
+  for (int w = tid; w < PW; w += kBlock) { tba[w] = 0; firsts[w] = 0; lasts[w] = 0; posm[w] = 0; }
   if (tid == 0) { s_maxpos = -1; s_any = 0; s_n = 0; s_P = 0; s_anydup = 0; }
 
   if (B <= 1 || (m.flags & 1)) {  // :86 (<=1 bubble) or a compiled-in limit  (uniform)
@@ -644,13 +687,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, Reads
 #define RS_T() do {} while (0)
 #endif
   // ---- phase A: the read-path CSR, once, coalesced -> one node bitset per alignment ----
-  const int wordsN = (m.N + 63) >> 6;
   const long long e_base = db.rnode_off[m.r0];
   for (int i = tid; i < wordsN * R; i += kBlock) bits[i] = 0ull;
   for (int r = tid; r <= R; r += kBlock) roff[r] = (unsigned int)(db.rnode_off[m.r0 + r] - e_base);
   // the allele paths as node masks (full path / inner nodes), once per chain
-  const long long a_base = db.allele_off[m.b0];
-  const int SA = (int)(db.allele_off[m.b0 + B] - a_base);
   for (int k = tid; k <= B; k += kBlock) ahead[k] = (unsigned short)(db.allele_off[m.b0 + k] - a_base);
   unsigned short* s1l = cidx;  // S1 visiting order (phase B only; cidx is written in phase D)
   for (int k = tid; k < B; k += kBlock) s1l[k] = (unsigned short)db.s1_order[m.b0 + k];
@@ -804,7 +844,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, Reads
   if (tid == 0) {
     // boundaries = {el, el+1 : el in lasts \ firsts}; to_be_added = [0,maxpos) U boundaries
     unsigned int carry = 0;
-    for (int w = 0; w < 32; w++) {
+    for (int w = 0; w < PW; w++) {
       unsigned int bd = lasts[w] & ~firsts[w];
       unsigned int t = bd | (bd << 1) | carry;
       carry = bd >> 31;
@@ -879,9 +919,11 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, Reads
       const int g = g0 + j * kBlock;
       int slot = atomicAdd(&s_n, 1);
       // creation order of the Read objects in partial_readset: (position, allele, alignment)
-      keys[slot] = ((unsigned)first[j] << 21) | ((unsigned)afirst[j] << 17) | (unsigned)rcre[j];
-      kname[slot] = (unsigned short)g;
-      kfirst[slot] = (unsigned short)first[j];
+      if (slot < capN) {  // (a readset beyond kMaxReads is reported below: its reads need no slot)
+        keys[slot] = ((unsigned)first[j] << 20) | ((unsigned)afirst[j] << 16) | (unsigned)rcre[j];  // (12-bit position, 4-bit allele, 16-bit alignment)
+        kname[slot] = (unsigned short)g;
+        kfirst[slot] = (unsigned short)first[j];
+      }
       if ((unsigned int)cv0[j]) atomicOr(&posm[0], (unsigned int)cv0[j]);
       if ((unsigned int)(cv0[j] >> 32)) atomicOr(&posm[1], (unsigned int)(cv0[j] >> 32));
       if ((unsigned int)cv1[j]) atomicOr(&posm[2], (unsigned int)cv1[j]);
@@ -911,7 +953,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, Reads
     unsigned int ki = keys[i];
     int rank = 0;
     for (int j = 0; j < n; j++) rank += (keys[j] < ki) ? 1 : 0;
-    srt[rank] = ((ki >> 21) << 16) | (unsigned)rank;
+    srt[rank] = ((ki >> 20) << 16) | (unsigned)rank;
     insname[rank] = kname[i];
     insfirst[rank] = kfirst[i];
   }
@@ -1059,7 +1101,7 @@ size_t readset_lds2_bytes(const ReadsetLds2& l) {
   b += (size_t)((l.maxB + 2) & ~1) * 2 * 2;   // cidx padding, ahead
   b += (size_t)((l.maxSA + 15) & ~15);        // adup
   b += (size_t)((l.maxR + 2) & ~1) * 4;       // roff
-  b += 4 * 32 * 4;                            // tba, firsts, lasts, posm
+  b += (size_t)4 * ((l.maxB + 32) >> 5) * 4;  // tba, firsts, lasts, posm
   b += (size_t)l.maxG * 4 * 2;                // keys, srt
   b += (size_t)l.maxG * 2 * 4;                // kname, insname, kfirst, insfirst
   b += (size_t)(l.maxB + 2) * 2;              // cidx
@@ -1099,11 +1141,11 @@ __global__ __launch_bounds__(64) void k_sortperm(DeviceBatch db, const int* __re
   }
 }
 
-void launch_readset_lds(const DeviceBatch& db, const int* list, int count, const ReadsetLds2& l, hipStream_t stream) {
+void launch_readset_lds(const DeviceBatch& db, const int* list, int count, size_t lds_bytes, int maxG, hipStream_t stream) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(k_readset_lds, dim3(count), dim3(kBlock), readset_lds2_bytes(l), stream, db, l, list);
-  const size_t cap = (size_t)((l.maxG + 1) & ~1);  // srt + tmp (u32), cutbit, posL + posR (u16)
-  hipLaunchKernelGGL(k_sortperm, dim3(count), dim3(64), cap * 12 + (cap / 32 + 4) * 4 + 32, stream, db, list, l.maxG);
+  hipLaunchKernelGGL(k_readset_lds, dim3(count), dim3(kBlock), lds_bytes, stream, db, list);
+  const size_t cap = (size_t)((maxG + 1) & ~1);  // srt + tmp (u32), cutbit, posL + posR (u16)
+  hipLaunchKernelGGL(k_sortperm, dim3(count), dim3(64), cap * 12 + (cap / 32 + 4) * 4 + 32, stream, db, list, maxG);
 }
 
 }  // namespace ahk

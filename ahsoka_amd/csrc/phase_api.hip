@@ -95,8 +95,14 @@ struct ahsoka_device_batch {
   std::vector<void*> ws_allocs;  // slot workspaces (released as a whole if their allocation fails)
   DeviceBatch db;
   ReadsetLds rl;
-  ReadsetLds2 rl2;
-  int* rs_list = nullptr;  // device: chains of k_readset_lds first, then those of k_readset
+  // k_readset_lds runs once per LDS class of its chains (by the chain's own LDS need: three, two or one
+  // workgroup per CU), so that a few large chains do not dictate the occupancy of the many small ones
+  struct RsClass {
+    size_t lds_bytes = 0;
+    int maxG = 1, first = 0, count = 0;
+  };
+  RsClass rs_class[3];
+  int* rs_list = nullptr;  // device: chains of k_readset_lds (class by class) first, then those of k_readset
   int n_fit = 0, n_big = 0, n_fit_real = 0;
   std::vector<PhaseClass> classes;
   int* qheads = nullptr;
@@ -337,8 +343,9 @@ static int upload_impl(const ahsoka_chain_batch* in, const ahsoka_phase_params* 
   std::vector<int> maxAv((size_t)C, 2);
   int maxA = 2, maxG = 1, maxB = 1, maxN = 1;
   long long vm = 0, fr = 0, cov = 0, dump = 0;
-  std::vector<int> fit_list, big_list;
-  h->rl2 = ReadsetLds2{1, 1, 1, 1, 1, 1};
+  std::vector<int> fit_list[3], big_list;
+  // LDS need up to which three / two workgroups of k_readset_lds share a CU (160 KB, some static LDS)
+  const size_t rs_limit[2] = {52 * 1024, 78 * 1024};
   h->maxB = 1;
   const size_t lds_per_block = h->lds_per_block;
   parallel_ranges(C, 8, [&](long long c0, long long c1) {
@@ -355,10 +362,10 @@ static int upload_impl(const ahsoka_chain_batch* in, const ahsoka_phase_params* 
       for (int r = 0; r < m.R; r++) G = std::max(G, in->read_name[m.r0 + r] + 1);
       m.G = G;
       m.Wb = (m.B + 63) / 64;
-      bool unsupported = m.B > kMaxBubbles || m.N > kMaxNodes || G > kMaxNames || m.R > 131071;
+      bool unsupported = m.B > kMaxBubbles || m.N > kMaxNodes || G > kMaxNames || m.R > kMaxAlns;
       // a chain whose k_readset working set does not fit this device's LDS is reported
       // per chain, like the compiled-in limits, instead of failing the whole batch
-      if (!unsupported && readset_lds_bytes(ReadsetLds{(m.N + 63) / 64, std::max(G, 1), std::max(m.B, 1)}) > lds_per_block)
+      if (!unsupported && readset_lds_bytes(ReadsetLds{std::min((m.N + 63) / 64, kWinWords), std::max(G, 1), std::max(m.B, 1)}) > lds_per_block)
         unsupported = true;
       int mA = 2;
       for (long long g = m.b0; g < m.b0 + m.B; g++) {
@@ -403,15 +410,14 @@ static int upload_impl(const ahsoka_chain_batch* in, const ahsoka_phase_params* 
     m.dump0 = -1;
     if (m.vmat0 >= 0) vm += (long long)m.R * m.B;
     if (fit) {
-      fit_list.push_back(c);
-      if (!unsupported && m.B > 1) {
+      const bool real = !unsupported && m.B > 1;
+      const size_t need = real ? readset_lds2_bytes(need2) : 0;
+      const int k = need <= rs_limit[0] ? 0 : need <= rs_limit[1] ? 1 : 2;
+      fit_list[k].push_back(c);
+      if (real) {
         h->n_fit_real++;
-        h->rl2.maxBitWords = std::max(h->rl2.maxBitWords, need2.maxBitWords);
-        h->rl2.maxMaskWords = std::max(h->rl2.maxMaskWords, need2.maxMaskWords);
-        h->rl2.maxSA = std::max(h->rl2.maxSA, need2.maxSA);
-        h->rl2.maxR = std::max(h->rl2.maxR, m.R);
-        h->rl2.maxG = std::max(h->rl2.maxG, std::max(G, 1));
-        h->rl2.maxB = std::max(h->rl2.maxB, std::max(m.B, 1));
+        h->rs_class[k].lds_bytes = std::max(h->rs_class[k].lds_bytes, need);
+        h->rs_class[k].maxG = std::max(h->rs_class[k].maxG, std::max(G, 1));
       }
     } else {
       big_list.push_back(c);
@@ -517,14 +523,20 @@ static int upload_impl(const ahsoka_chain_batch* in, const ahsoka_phase_params* 
   db.affine_cost = prm->affine_switch_cost;
 
   // ---- kernel geometry ----------------------------------------------------------
-  h->rl.wordsN = (maxN + 63) / 64;
+  h->rl.wordsN = std::min((maxN + 63) / 64, kWinWords);  // (k_readset's per-alignment node window)
   h->rl.maxG = maxG;
   h->rl.maxB = maxB;
   h->maxG = maxG;
-  h->n_fit = (int)fit_list.size();
   h->n_big = (int)big_list.size();
   {
-    std::vector<int> both(fit_list);
+    std::vector<int> both;
+    for (int k = 0; k < 3; k++) {
+      h->rs_class[k].first = (int)both.size();
+      h->rs_class[k].count = (int)fit_list[k].size();
+      if (h->rs_class[k].lds_bytes < 1024) h->rs_class[k].lds_bytes = 1024;  // (a class of skipped chains only)
+      both.insert(both.end(), fit_list[k].begin(), fit_list[k].end());
+    }
+    h->n_fit = (int)both.size();
     both.insert(both.end(), big_list.begin(), big_list.end());
     const int* q = nullptr;
     if ((rc = h->dupload(&q, both.data(), both.size()))) return fail(rc);
@@ -765,7 +777,8 @@ static int phase_device_impl(ahsoka_device_batch* h) {
   if (h->C == 0) return AHSOKA_OK;
   auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-  launch_readset_lds(h->db, h->rs_list, h->n_fit, h->rl2, h->stream);
+  for (const ahsoka_device_batch::RsClass& rc : h->rs_class)
+    launch_readset_lds(h->db, h->rs_list + rc.first, rc.count, rc.lds_bytes, rc.maxG, h->stream);
   launch_readset(h->db, h->rs_list + h->n_fit, h->n_big, h->rl, h->stream);
   HIP_TRY(hipGetLastError());
   if (!h->ws_ready) {  // first call only: size classes and slot pools from the real readsets

@@ -204,15 +204,20 @@ void score_readset_local(const std::vector<ORead>& reads, int min_overlap, int p
       if (j == i) continue;
       uint32_t o = (uint32_t)ov[(size_t)i * n + j], d = (uint32_t)df[(size_t)i * n + j];
       if ((int)o < min_overlap || o == 0) continue;
-      keys.push_back((((d << 20) / o) << 10) | o);  // (rate, overlap): exact order for o <= 1023
+      // (rate, overlap): exact order for o <= 4095.  d == o gives rate 2^20, the only value above
+      // 2^20 - 2^20/o: it is stored as 2^20 - 2 (same place in the order, d still recovered below) so
+      // that the key fits 32 bits with a 12-bit overlap field
+      uint32_t rate = (d << 20) / o;
+      if (rate > (1u << 20) - 2u) rate = (1u << 20) - 2u;
+      keys.push_back((rate << 12) | o);
     }
     std::sort(keys.begin(), keys.end());
     size_t m = keys.size() / (size_t)ploidy;
     if (m == 0 && !keys.empty()) m = 1;
     int64_t ds = 0, os = 0, dr = 0, orr = 0;
     for (size_t k = 0; k < keys.size(); k++) {
-      uint32_t o = keys[k] & 1023u;
-      uint32_t rate = keys[k] >> 10;
+      uint32_t o = keys[k] & 4095u;
+      uint32_t rate = keys[k] >> 12;
       // recover d: d = ceil(rate*o / 2^20) is exact because rate = floor(d*2^20/o)
       uint64_t dd = ((uint64_t)rate * o + ((1u << 20) - 1)) >> 20;
       if (k < m) { ds += (int64_t)dd; os += o; }

@@ -259,11 +259,12 @@ def _concat(parts):
 
 def test_over_limit_chain_is_reported_per_chain():
     """a chain beyond a device limit comes back AHSOKA_ST_UNSUPPORTED; the other chains of the
-    batch are phased as usual (the limits: phase_kernels.h)"""
+    batch are phased as usual (the limits: phase_kernels.h -- 8192 names, 8192 nodes, 4096 final
+    reads, 4095 bubbles)"""
     ok = capi.synth_batch(n_chains=3, n_bubbles=9, n_reads=80, seed=5).arrays()
-    many_names = capi.synth_batch(n_chains=1, n_bubbles=12, n_reads=4300, seed=6).arrays()   # > 4096 names
-    many_nodes = capi.synth_batch(n_chains=1, n_bubbles=700, n_reads=50, seed=7).arrays()    # 2101 nodes > 2048
-    many_final = capi.synth_batch(n_chains=1, n_bubbles=40, n_reads=3600, seed=8).arrays()   # > 2048 final reads
+    many_names = capi.synth_batch(n_chains=1, n_bubbles=12, n_reads=8300, seed=6).arrays()   # > 8192 names
+    many_nodes = capi.synth_batch(n_chains=1, n_bubbles=2800, n_reads=50, seed=7).arrays()   # 8401 nodes > 8192
+    many_final = capi.synth_batch(n_chains=1, n_bubbles=40, n_reads=8000, seed=8).arrays()   # > 4096 final reads
     b = _concat([ok, many_names, many_nodes, many_final])
     g = capi.phase_batch(b, capi.default_params())
     assert g.status.tolist() == [0, 0, 0, capi.ST_UNSUPPORTED, capi.ST_UNSUPPORTED, capi.ST_UNSUPPORTED]
@@ -271,6 +272,40 @@ def test_over_limit_chain_is_reported_per_chain():
     np.testing.assert_array_equal(g.hap_allele, o.hap_allele)
     np.testing.assert_array_equal(g.pos, o.pos)
     assert g.n_reads[3:].sum() == 0 and g.pos_off[-1] == o.pos_off[-1]
+
+
+def test_chains_beyond_the_round2_limits_are_phased():
+    """the reference's chain loop has no size limit (src/alignmentstoreadset.cpp:75-490).  Chains the
+    round-2 kernels refused -- a 1500-bubble chain at 40x depth (4501 nodes, 5455 read names, ~3500
+    final reads: a real-shape hifiasm chain), a 40-bubble chain whose 3600 reads leave ~2100 final
+    reads that nearly all overlap (150 000 iterations), and a 700-bubble chain (2101 nodes) -- are
+    phased and bit-equal to the oracle, stage dumps of the long chain included; the three go
+    through ONE batch, i.e. through the windowed fallback readset kernel, the 64-word bitmap rows
+    and the 12-bit edge keys of k_phase, next to an ordinary chain."""
+    import concurrent.futures as cf
+
+    parts = [capi.synth_batch(n_chains=1, n_bubbles=1500, n_reads=5455, seed=9, mean_span=10.0).arrays(),
+             capi.synth_batch(n_chains=1, n_bubbles=40, n_reads=3600, seed=8).arrays(),
+             capi.synth_batch(n_chains=1, n_bubbles=700, n_reads=900, seed=7).arrays(),
+             capi.synth_batch(n_chains=2, n_bubbles=9, n_reads=80, seed=5).arrays()]
+    b = _concat(parts)
+    g = capi.phase_batch(b, capi.default_params())
+    assert (g.status == capi.ST_PHASED).all()
+    assert g.n_reads[0] > 3000 and g.n_reads[1] > 2048 and np.diff(g.pos_off)[0] > 1400
+    # the oracle is single-threaded per chain (~100 s for each of the two large ones): one thread per chain
+    with cf.ThreadPoolExecutor(4) as ex:
+        outs = list(ex.map(lambda a: ob.phase_batch(capi.ChainBatch(arrays=a), capi.default_params(), n_threads=2), parts))
+    c = 0
+    for o in outs:
+        for lc in range(o.n_chains):
+            assert g.status[c] == o.status[lc]
+            assert g.n_reads[c] == o.n_reads[lc] and g.n_clusters[c] == o.n_clusters[lc]
+            assert g.n_iterations[c] == o.n_iterations[lc], (c, g.n_iterations[c], o.n_iterations[lc])
+            np.testing.assert_array_equal(g.chain_pos(c), o.chain_pos(lc))
+            np.testing.assert_array_equal(g.chain_haps(c), o.chain_haps(lc))
+            c += 1
+    # all stages of a mid-size chain beyond the old node limit, through one slot
+    _compare(capi.ChainBatch(arrays=parts[2]), capi.default_params(want_stages=1, max_slots=1))
 
 
 def test_c5_full_size_vs_oracle():
