@@ -64,6 +64,7 @@ class CPhaseParams(C.Structure):
         ("max_slots", C.c_int32),
         ("symmetry_opt", C.c_int32),
         ("row_limit", C.c_int32),
+        ("wave_mode", C.c_int32),
     ]
 
 

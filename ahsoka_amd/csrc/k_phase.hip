@@ -386,11 +386,11 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
 }
 
 // rows dlist[0..nd): wave wv takes pairs of rows
-template <class IcT>
+template <class IcT, int NWV>
 __device__ __forceinline__ void rescan_list(const unsigned short* dlist, int nd, int wv, int lane, int n, int nw,
                                             const unsigned long long* __restrict__ LV, const IcT* __restrict__ IC,
                                             unsigned long long* bestF, unsigned long long* bestP) {
-  for (int di = 2 * wv; di < nd; di += 8) {
+  for (int di = 2 * wv; di < nd; di += 2 * NWV) {
     // (the rows are wave-uniform: as scalars, their address arithmetic runs on the scalar unit)
     const int r0 = __builtin_amdgcn_readfirstlane((int)dlist[di]);
     const int r1 = di + 1 < nd ? __builtin_amdgcn_readfirstlane((int)dlist[di + 1]) : -1;
@@ -608,11 +608,18 @@ constexpr int kInitRows = AHK_INIT_ROWS;  // consecutive rows a wave of S5-init 
 // kernel is bound by those (+10 % at config 3).  A chain that fails the test right after S4b is
 // put on the `deferred` list and left to the 64-bit instance, launched behind this one with that
 // list as its queue (Cdev = its length, on the device).
-template <bool IC32>
-__global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
+// NWV: wavefronts per workgroup.  4 is the throughput form (five workgroups per CU, 1280 chains in
+// flight); 8 and 16 are the LATENCY forms for a size class whose chains all have a CU (or half of
+// one) to themselves -- config 5's largest chains, a batch of few chains, a shard at N = 8: the
+// trip-count-bound passes of an iteration (candidate listing, edge pass, rescans, heavy chunks,
+// S5 init, S4) shorten with the lane count, the strictly sequential parts (argmax, the two
+// dependent round trips of a single-read separation) do not.  Results do not depend on NWV.
+template <bool IC32, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k_phase_t(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
                                                        int C, const int* __restrict__ Cdev, int* __restrict__ qhead,
                                                        int* __restrict__ deferred, int* __restrict__ ndeferred) {
   using IcT = typename std::conditional<IC32, IcPair32, IcPair>::type;
+  constexpr int kThreads = NWV * 64;
   if (Cdev) C = *Cdev;
   extern __shared__ __align__(16) unsigned long long smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -639,17 +646,22 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
   unsigned short* dlist = rowbuf + (lds.items_lds ? 4 * (size_t)nmax : 0);  // [nmax] rows whose maximum must be rescanned
   unsigned int* multiw = (unsigned int*)(dlist + nmax);   // [nmax/32] bit per read: its clique has > 1 member
   // words of a bitmap row the class can have: 32 (n <= 2048) or 64 -- sizes the per-word role tables
-  const int RW = lds.nmax > 2048 ? 64 : 32;
+  // (and, in the wide forms, room for the per-wave pending lists that re-use the tables: 128 u32 per wave)
+  const int RW = (lds.nmax > 2048 ? 64 : 32) > NWV * 8 ? (lds.nmax > 2048 ? 64 : 32) : NWV * 8;
   unsigned long long* rmask = (unsigned long long*)(multiw + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][RW] role masks per 64-column word
   unsigned long long* rolenz = rmask + 4 * RW;             // [4][RW] OR of the members' nz-rows
   unsigned char* role = (unsigned char*)(rolenz + 4 * RW);  // [nmax]
   int* wrow = (int*)(role + nmax);                         // [nmax] weights of a single read's row (see "staged row")
+  // per-wave scratch of S4a (key buffer, u32) and S5 init (neighbour list, u16): the four-wave form
+  // re-uses bestF/bestP and the role lists, which hold exactly four such buffers; the wide forms
+  // have a region of their own (one workgroup or two per CU: the LDS is there)
+  unsigned int* wscr = NWV > 4 ? (unsigned int*)(((size_t)(wrow + (lds.stage_row ? nmax : 0)) + 7) & ~(size_t)7) : nullptr;  // [NWV][nmax]
   __shared__ int s_chain, s_cnt[4], s_nd, s_items, s_nh, s_nslow;
   __shared__ unsigned short s_pref[4][64];
 #ifdef AHK_TIMING
   __shared__ int s_chg;
 #endif
-  __shared__ unsigned long long s_rk[16];
+  __shared__ unsigned long long s_rk[2 * NWV < 16 ? 16 : 2 * NWV];
 #ifdef AHK_FTRACE
   __shared__ unsigned long long s_ft[4][16];
   long long ftl = 0;
@@ -689,8 +701,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
 
     // ================= S4a: per-read local Hamming-rate estimates ==========
     {
-      unsigned int* keybuf = (unsigned int*)bestF + (size_t)wv * nmax;  // 4 waves x nmax u32 = 16*nmax bytes
-      for (int i = wv; i < n; i += 4) {
+      unsigned int* keybuf = (NWV > 4 ? wscr : (unsigned int*)bestF) + (size_t)wv * nmax;  // (4 waves x nmax u32 = 16*nmax bytes = bestF + bestP)
+      for (int i = wv; i < n; i += NWV) {
         int cnt = 0;
         long long dall = 0, oall = 0;
         for (int j = lane; j < n; j += 64) {
@@ -762,7 +774,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
 
     // ================= S4b: similarity matrix W ============================
     long long smax = 0;  // (this wave's rows) largest row sum of |W|: decides whether 32-bit induced costs are exact
-    for (int i = wv; i < n; i += 4) {
+    for (int i = wv; i < n; i += NWV) {
       const double si = rates[i], fi = rates[n + i];
       long long srow = 0;
       for (int j = lane; j < n; j += 64) {
@@ -787,7 +799,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
       smax = srow > smax ? srow : smax;
     }
     if (lane == 0) s_rk[wv] = (unsigned long long)smax;
-    for (int u = tid; u < n; u += kBlock) {
+    for (int u = tid; u < n; u += kThreads) {
       cl[u] = (unsigned short)u;
       role[u] = ROLE_NONE;
     }
@@ -797,7 +809,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
       // the wide instance (uniform: every wave reads the same four values); the wide instance in turn needs the
       // value to fit the 39-bit field of the packed edge keys
       unsigned long long sm = s_rk[0];
-      for (int k = 1; k < 4; k++) sm = s_rk[k] > sm ? s_rk[k] : sm;
+      for (int k = 1; k < NWV; k++) sm = s_rk[k] > sm ? s_rk[k] : sm;
       if (IC32) {
         if (2ull * sm >= (1ull << 32)) {
           if (tid == 0) deferred[atomicAdd(ndeferred, 1)] = c;
@@ -838,14 +850,15 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
     // per wave re-read each chain's 1.4 MB of weights ~30 times (a fifth of the kernel's HBM
     // traffic, round 2); four rows per group make a quarter of those gathers and drop the
     // v_readlane of the row weight from three of four terms.
-    for (int u = tid; u < n; u += kBlock) { bestF[u] = 0ull; bestP[u] = 0ull; }
+    for (int u = tid; u < n; u += kThreads) { bestF[u] = 0ull; bestP[u] = 0ull; }
     __syncthreads();
     {
       // induced costs of a narrow (IC32) chain are < 2^32 and sums of non-negative terms: 32-bit
       // unsigned accumulators are exact there
       using AccT = typename std::conditional<IC32, unsigned int, long long>::type;
-      unsigned short* nbr = listA + (size_t)wv * nmax;   // union of the group's neighbours, ascending (the role lists are free here)
-      for (int a0 = wv * kInitRows; a0 < n; a0 += 4 * kInitRows) {
+      unsigned short* nbr = NWV > 4 ? (unsigned short*)(wscr + (size_t)wv * nmax)
+                                    : listA + (size_t)wv * nmax;   // union of the group's neighbours, ascending (the role lists are free here)
+      for (int a0 = wv * kInitRows; a0 < n; a0 += NWV * kInitRows) {
         const int R = n - a0 < kInitRows ? n - a0 : kInitRows;
         int deg = 0, dhi = 0;
         for (int w0 = 0; w0 < n; w0 += 64) {
@@ -928,7 +941,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         }
       }
     }
-    for (int u = tid; u < (n + 31) / 32; u += kBlock) multiw[u] = 0;
+    for (int u = tid; u < (n + 31) / 32; u += kThreads) multiw[u] = 0;
     if (tid < 4) s_cnt[tid] = 0;
     if (tid == 0) { s_nd = 0; s_items = 0; s_nh = 0; s_nslow = 0; }
     __syncthreads();
@@ -968,7 +981,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         // heuristic's tie rule is one 64-bit max over them, and its stale bit says
         // whether a stale bound ties the maximum
         unsigned long long gF = 0ull, gP = 0ull;
-        for (int u = tid; u < n; u += kBlock) {
+        for (int u = tid; u < n; u += kThreads) {
           const unsigned long long k1 = bestF[u], k2 = bestP[u];
           gF = k1 > gF ? k1 : gF;
           gP = k2 > gP ? k2 : gP;
@@ -977,15 +990,15 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         gF = wave_max_u64(gF);
         gP = wave_max_u64(gP);
         if (lane == 0) {
-          s_rk[wv] = gF; s_rk[4 + wv] = gP;
+          s_rk[wv] = gF; s_rk[NWV + wv] = gP;
         }
         AHK_F(1);
         __syncthreads();
         AHK_F(2);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < NWV; k++) {
           gF = s_rk[k] > gF ? s_rk[k] : gF;
-          gP = s_rk[4 + k] > gP ? s_rk[4 + k] : gP;
+          gP = s_rk[NWV + k] > gP ? s_rk[NWV + k] : gP;
         }
         gF = readlane_u64(gF, 0);  // (every lane holds the same two keys: make them scalars)
         gP = readlane_u64(gP, 0);
@@ -997,14 +1010,14 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         AHK_T(0);
         if (!need) break;  // uniform
         // collect the stale rows whose bound ties a maximum, rescan them exactly
-        for (int u = tid; u < n; u += kBlock) {
+        for (int u = tid; u < n; u += kThreads) {
           const unsigned long long k1 = bestF[u], k2 = bestP[u];
           if (((k1 & kStale) && (k1 >> kKeyValShift) == (gF >> kKeyValShift)) || ((k2 & kStale) && (k2 >> kKeyValShift) == (gP >> kKeyValShift)))
             dlist[atomicAdd(&s_nd, 1)] = (unsigned short)u;
         }
         __syncthreads();
         {
-          rescan_list(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
+          rescan_list<IcT, NWV>(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
         }
         __syncthreads();
 #ifdef AHK_TIMING
@@ -1031,7 +1044,8 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
       // trips per iteration instead of about ten.
       AHK_F(3);
       if (!merge && !(((multiw[eu >> 5] >> (eu & 31)) | (multiw[ev >> 5] >> (ev & 31))) & 1u)) {
-        const int half = wv >> 1, sub = wv & 1;
+        constexpr int NSUB = NWV / 2;  // waves per row
+        const int half = wv / NSUB, sub = wv % NSUB;
         const int x = half ? ev : eu, w = half ? eu : ev;
         unsigned long long lvn = 0ull, nzo = 0ull;
         if (lane < nw) {
@@ -1046,15 +1060,19 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         unsigned long long todo = __ballot(lvn != 0ull);
         unsigned long long kF = 0ull, kP = 0ull;
         AHK_F(4);
-        // this wave takes the live words of even (sub 0) / odd (sub 1) rank, kFastBatch per trip
+        // this wave takes the live words whose rank is sub modulo NSUB (four waves: even / odd rank), kFastBatch per trip
         while (todo != 0ull) {
           int lw[kFastBatch];
 #pragma unroll
           for (int c = 0; c < kFastBatch; c++) {
-            if (sub && todo != 0ull) todo &= todo - 1ull;
+#pragma unroll
+            for (int q = 0; q < NSUB - 1; q++)
+              if (q < sub && todo != 0ull) todo &= todo - 1ull;
             lw[c] = todo != 0ull ? __builtin_ctzll(todo) : -1;
             if (todo != 0ull) todo &= todo - 1ull;
-            if (!sub && todo != 0ull) todo &= todo - 1ull;
+#pragma unroll
+            for (int q = 0; q < NSUB - 1; q++)
+              if (q >= sub && todo != 0ull) todo &= todo - 1ull;
           }
           IcT icv[kFastBatch];
           int wb[kFastBatch];
@@ -1101,15 +1119,21 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         AHK_F(5);
         kF = wave_max_u64(kF);
         kP = wave_max_u64(kP);
-        if (lane == 0) { s_rk[wv] = kF; s_rk[4 + wv] = kP; }
+        if (lane == 0) { s_rk[wv] = kF; s_rk[NWV + wv] = kP; }
         AHK_F(6);
         __syncthreads();
         AHK_F(7);
         if (tid < 2) {
           const int xr = tid ? ev : eu;
-          const unsigned long long a1 = s_rk[2 * tid], a2 = s_rk[2 * tid + 1], b1 = s_rk[4 + 2 * tid], b2 = s_rk[4 + 2 * tid + 1];
-          bestF[xr] = a1 > a2 ? a1 : a2;
-          bestP[xr] = b1 > b2 ? b1 : b2;
+          unsigned long long a1 = 0ull, b1 = 0ull;  // (the row's waves: NSUB partial maxima each)
+#pragma unroll
+          for (int q = 0; q < NSUB; q++) {
+            const unsigned long long a2 = s_rk[NSUB * tid + q], b2 = s_rk[NWV + NSUB * tid + q];
+            a1 = a2 > a1 ? a2 : a1;
+            b1 = b2 > b1 ? b2 : b1;
+          }
+          bestF[xr] = a1;
+          bestP[xr] = b1;
           WM_AT((unsigned)(xr * n + (tid ? eu : ev))) = W_FORB;  // every wave has read the old weight by now
         }
         __syncthreads();
@@ -1136,13 +1160,13 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
       const int rs = !lds.stage_row ? -1
                                     : __builtin_amdgcn_readfirstlane(!((multiw[eu >> 5] >> (eu & 31)) & 1u) ? eu : (!((multiw[ev >> 5] >> (ev & 31)) & 1u) ? ev : -1));
       if (rs >= 0)
-        for (int z = tid; z < n; z += kBlock) wrow[z] = WM_AT((unsigned)(rs * n + z));
+        for (int z = tid; z < n; z += kThreads) wrow[z] = WM_AT((unsigned)(rs * n + z));
 
       // ---- P2: roles, member lists and per-word role masks --------------------
       // (s_cnt was zeroed before the last barrier).  rmask[R][k] has bit c set iff
       // column 64k+c plays role R: the row passes below work on whole 64-column
       // words with these masks instead of looking at single columns.
-      for (int z0 = 0; z0 < nw * 64; z0 += kBlock) {
+      for (int z0 = 0; z0 < nw * 64; z0 += kThreads) {
         const int z = z0 + tid;
         int r = ROLE_NONE;
         if (z < n) {
@@ -1171,7 +1195,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
       // popcounts of role R, then every member finds its slot by a popcount below its bit
       // (consecutive list entries are neighbouring columns: the row accesses W[x][w] over a
       // list touch few lines, and the heavy-edge pass relies on the order)
-      {
+      if (wv < 4) {  // (four roles: waves 0..3)
         const unsigned long long mw = lane < nw ? rmask[wv * RW + lane] : 0ull;
         const int pc = __popcll(mw);
         const int incl = wave_scan_i(pc);
@@ -1179,7 +1203,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         if (lane == 63) s_cnt[wv] = incl;
       }
       __syncthreads();
-      for (int z = tid; z < n; z += kBlock) {
+      for (int z = tid; z < n; z += kThreads) {
         const int r = role[z];
         if (r == ROLE_NONE) continue;
         const int k = z >> 6;
@@ -1205,7 +1229,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
       // ---- P2b: per role, the OR of the nz-rows of its members (wave R <-> role R):
       // "some member w of the role has W[w][b] != 0".  One pass per iteration,
       // shared by every row of P3a; lists longer than 32 are not filtered.
-      {
+      if (wv < 4) {
         const unsigned short* Lr = wv == 0 ? listA : wv == 1 ? listB : wv == 2 ? listFa : listFb;
         const int nr = wv == 0 ? nA : wv == 1 ? nB : wv == 2 ? nFa : nFb;
         unsigned long long acc = 0ull;
@@ -1263,17 +1287,17 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         // the bitmap words of pass k+1 are requested before pass k is processed: with
         // hundreds of rewritten rows (a large clique) every pass would otherwise wait
         // for its own HBM round trip
-        int x_nx = row_of(wv * RP + slot);
+        int x_nx = row_of(wv * RP + slot);  // (a workgroup pass handles NWV * RP rows)
         unsigned long long lv_nx = 0ull, nz_nx = 0ull;
         if (x_nx >= 0 && wordok) {
           lv_nx = LV_AT((unsigned)(x_nx * nw + kw));
           nz_nx = NZ_AT((unsigned)(x_nx * nw + kw));
         }
-        for (int xi0 = wv * RP; xi0 < nT; xi0 += 4 * RP) {
+        for (int xi0 = wv * RP; xi0 < nT; xi0 += NWV * RP) {
           const int xi = xi0 + slot;
           const int x = x_nx;
           const unsigned long long lvw = lv_nx, nzw = nz_nx;
-          x_nx = row_of(xi + 4 * RP);
+          x_nx = row_of(xi + NWV * RP);
           lv_nx = 0ull;
           nz_nx = 0ull;
           if (x_nx >= 0 && wordok) {
@@ -1624,14 +1648,14 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
           auto fetch = [&](const int i) -> unsigned int { return i < M ? (i < cap ? items_lds[i] : items_glb[i - cap]) : 0u; };
           unsigned int q[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) q[u] = fetch(tid + u * kBlock);
-          for (int i0 = 0; i0 < M; i0 += 4 * kBlock) {
+          for (int u = 0; u < 4; u++) q[u] = fetch(tid + u * kThreads);
+          for (int i0 = 0; i0 < M; i0 += 4 * kThreads) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-              const int ib = i0 + u * kBlock;
+              const int ib = i0 + u * kThreads;
               if (ib < M) {  // uniform
                 const unsigned int it = q[u];
-                q[u] = fetch(ib + tid + 4 * kBlock);
+                q[u] = fetch(ib + tid + 4 * kThreads);
                 classify(it, ib + tid < M);
               }
             }
@@ -1665,9 +1689,9 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
           };
           unsigned int it_nx = 0u;
           if (tid < cnt0 + cnt1) it_nx = fetchB(tid);
-          for (int i = tid; i < cnt0 + cnt1; i += kBlock) {
+          for (int i = tid; i < cnt0 + cnt1; i += kThreads) {
             const unsigned int it = it_nx;
-            if (i + kBlock < cnt0 + cnt1) it_nx = fetchB(i + kBlock);
+            if (i + kThreads < cnt0 + cnt1) it_nx = fetchB(i + kThreads);
             plain_item(it, (int)(it >> 28), (int)((it >> 24) & 7u));
           }
         }
@@ -1694,7 +1718,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
           unsigned long long* hacc = rmask;  // [2 * kHeavyCap]: rmask and rolenz are dead after P3a
           for (int r0 = 0; r0 < nh; r0 += kHeavyCap) {
             const int nr = nh - r0 < kHeavyCap ? nh - r0 : kHeavyCap;
-            for (int k = tid; k < 2 * nr; k += kBlock) hacc[k] = 0ull;
+            for (int k = tid; k < 2 * nr; k += kThreads) hacc[k] = 0ull;
             __syncthreads();
             // chunks per edge: the largest count over the heavy roles spans the grid
             int chmax = 0;
@@ -1708,7 +1732,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
               if (((heavy >> ROLE_FB) & 1u) && cFb > chmax) chmax = cFb;
             }
             const int V = nr * chmax;
-            for (int v = tid; v < V; v += kBlock) {
+            for (int v = tid; v < V; v += kThreads) {
               const int c = v / nr, hh = v - c * nr;
               const unsigned int it = hl[r0 + hh];
               const int rx = (int)(it >> 28);
@@ -1733,7 +1757,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
               if (dp != 0) atomicAdd(&hacc[2 * hh + 1], (unsigned long long)dp);
             }
             __syncthreads();
-            for (int hh0 = 0; hh0 < nr; hh0 += kBlock) {
+            for (int hh0 = 0; hh0 < nr; hh0 += kThreads) {
               const int hh = hh0 + tid;
               long long df = 0, dp = 0;
               if (hh < nr) {
@@ -1859,7 +1883,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         {
           const int ny = nB + nFb;
           const int np1 = nA * ny, np2 = nB * nFa;
-          for (int i = tid; i < np1 + np2; i += kBlock) {
+          for (int i = tid; i < np1 + np2; i += kThreads) {
             int x, y, N;
             if (i < np1) {
               const int xi = i / ny, yi = i - xi * ny;
@@ -1878,12 +1902,12 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
           }
         }
         if (merge) {
-          for (int yi = tid; yi < nB; yi += kBlock) {
+          for (int yi = tid; yi < nB; yi += kThreads) {
             const int y = listB[yi];
             cl[y] = (unsigned short)cu;
             atomicOr(&multiw[y >> 5], 1u << (y & 31));
           }
-          for (int xi = tid; xi < nA; xi += kBlock) {
+          for (int xi = tid; xi < nA; xi += kThreads) {
             const int x = listA[xi];
             atomicOr(&multiw[x >> 5], 1u << (x & 31));
           }
@@ -1892,7 +1916,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         if (tid == 0) { s_items = 0; s_nh = 0; s_nslow = 0; }
         AHK_T(6);  // (diagnostic build: weight rewrites vs rescans)
         // rows whose maximum died: exact rescan now (they would tie the next argmax anyway)
-        rescan_list(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
+        rescan_list<IcT, NWV>(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
         AHK_T(7);
       }
       __syncthreads();
@@ -1967,9 +1991,9 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
     // ---- clusters: ordered by smallest member ------------------------------
     // (bestF is free now: reuse as scratch)
     unsigned int* scratch = (unsigned int*)bestF;  // [4*nmax] u32 available
-    for (int u = tid; u < n; u += kBlock) scratch[u] = 0xFFFFFFFFu;
+    for (int u = tid; u < n; u += kThreads) scratch[u] = 0xFFFFFFFFu;
     __syncthreads();
-    for (int u = tid; u < n; u += kBlock) atomicMin(&scratch[cl[u]], (unsigned)u);
+    for (int u = tid; u < n; u += kThreads) atomicMin(&scratch[cl[u]], (unsigned)u);
     __syncthreads();
     if (wv == 0) {
       int base = 0;
@@ -1984,13 +2008,13 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
     }
     __syncthreads();
     const int K = __builtin_amdgcn_readfirstlane(s_back);
-    for (int u = tid; u < n; u += kBlock) {
+    for (int u = tid; u < n; u += kThreads) {
       const int kc = (int)scratch[nmax + scratch[cl[u]]];
       db.fr_cluster[m.fr0 + u] = kc;
       scratch[2 * (size_t)nmax + u] = (unsigned)kc;
     }
     __syncthreads();
-    for (int u = tid; u < n; u += kBlock) cl[u] = (unsigned short)scratch[2 * (size_t)nmax + u];
+    for (int u = tid; u < n; u += kThreads) cl[u] = (unsigned short)scratch[2 * (size_t)nmax + u];
     if (tid == 0) {
       db.nclusters[c] = K;
       db.niter[c] = iters;
@@ -2001,9 +2025,9 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
     const int P = cx.P;
     const int nA_all = 1 << cx.planes;
     {
-      unsigned int* hist = (unsigned int*)bestF + (size_t)wv * nmax;  // per wave, [K]
-      unsigned int* sb = sortbuf + (size_t)wv * ws.nmax;
-      for (int j = wv; j < P; j += 4) {
+      unsigned int* hist = (unsigned int*)bestF + (size_t)(wv & 3) * nmax;  // per wave, [K]
+      unsigned int* sb = sortbuf + (size_t)(wv & 3) * ws.nmax;
+      for (int j = wv; j < P && wv < 4; j += 4) {  // (per-wave histogram and sort buffer: four waves)
         for (int k = lane; k < K; k += 64) hist[k] = 0;
         const int wj = j >> 6, bj = j & 63;
         int tot = 0;
@@ -2025,7 +2049,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
         }
         // sort(): by coverage descending, std::sort from ascending-id order (:707-727)
         __threadfence_block();  // sb is global memory shared between the lanes of this wave
-        if (lane < 8) s_asc[wv][lane] = lane < M ? (int)sb[lane] : 0;
+        if (lane < 8) s_asc[wv & 3][lane] = lane < M ? (int)sb[lane] : 0;
         if (lane == 0) gnu_sort(sb, M, GreaterCnt());
         __threadfence_block();
         // get_pos_to_clusters_map cut-off (:763-772)
@@ -2073,7 +2097,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
           } else {
             // reference compaction (:379-402): coverage = i-th cluster present at the
             // position in ascending id; consensus = i-th covMap cluster in ascending id
-            tp_cov[(size_t)j * 8 + lane] = (double)((unsigned)s_asc[wv][lane] >> 16) / (double)tot;
+            tp_cov[(size_t)j * 8 + lane] = (double)((unsigned)s_asc[wv & 3][lane] >> 16) / (double)tot;
           }
         }
         if (db.compaction_mode == 0) {
@@ -2097,7 +2121,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
     {
       const long long Tmax = ws.Tmax;
       {
-        for (int j = wv; j < P; j += 4) {  // one wave per position
+        for (int j = wv; j < P; j += NWV) {  // one wave per position
           const int k = tp_k[j];
           int T = 1;
           for (int i = 0; i < ploidy; i++) T *= k;
@@ -2144,7 +2168,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
       for (int j = 0; j < P; j++) {
         const int k = tp_k[j], nt = tp_ntup[j];
         const int kp = j > 0 ? tp_k[j - 1] : 1, ntp = j > 0 ? tp_ntup[j - 1] : 0;
-        for (int r = tid; r < nt; r += kBlock) {
+        for (int r = tid; r < nt; r += kThreads) {
           int t[kMaxPloidy], g[kMaxPloidy];
           int rem = tp_tuples[(size_t)j * Tmax + r];
           for (int i = ploidy - 1; i >= 0; i--) { t[i] = rem % k; rem /= k; }
@@ -2194,9 +2218,9 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
           unsigned int* tabQ = (unsigned int*)(tabS + pw[ploidy - 1]);                      // [kp^(p-1)] lowest index reaching it
           const int* tup_prev = tp_tuples + (size_t)(j - 1) * Tmax;
           const double* sc_prev = tp_score + (size_t)(j - 1) * Tmax;
-          for (int cidx2 = tid; cidx2 < ncode; cidx2 += kBlock) idxmap[cidx2] = 0xffffu;
+          for (int cidx2 = tid; cidx2 < ncode; cidx2 += kThreads) idxmap[cidx2] = 0xffffu;
           __syncthreads();
-          for (int q = tid; q < ntp; q += kBlock) idxmap[tup_prev[q]] = (unsigned short)q;
+          for (int q = tid; q < ntp; q += kThreads) idxmap[tup_prev[q]] = (unsigned short)q;
           __syncthreads();
           // slot i of tuple r lives in cluster gcid[j][t_i]: its index among the previous
           // position's clusters (or -1) -- per thread, eight clusters at most
@@ -2217,7 +2241,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
             return v;
           };
           // S = all slots: exact predecessor with the same clusters
-          for (int r = tid; r < nt; r += kBlock) {
+          for (int r = tid; r < nt; r += kThreads) {
             int rem = tp_tuples[(size_t)j * Tmax + r];
             int code = 0;
             bool ok = true;
@@ -2243,10 +2267,10 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
           for (int S = 0; S < nsub; S++) {
             const int nS = __popc((unsigned)S), sw = ploidy - nS;
             const int nent = pw[nS];
-            for (int e = tid; e < nent; e += kBlock) { tabS[e] = ~0ull; tabQ[e] = 0xffffffffu; }
+            for (int e = tid; e < nent; e += kThreads) { tabS[e] = ~0ull; tabQ[e] = 0xffffffffu; }
             __syncthreads();
             for (int pass = 0; pass < 2; pass++) {
-              for (int q = tid; q < ntp; q += kBlock) {
+              for (int q = tid; q < ntp; q += kThreads) {
                 int rem = tup_prev[q];
                 int idx = 0, mul = 1;
                 for (int i = ploidy - 1; i >= 0; i--) {
@@ -2261,7 +2285,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
               __syncthreads();
             }
             const double add = db.switch_cost * (double)sw + (sw > 0 ? db.affine_cost : 0.0);
-            for (int r = tid; r < nt; r += kBlock) {
+            for (int r = tid; r < nt; r += kThreads) {
               int rem = tp_tuples[(size_t)j * Tmax + r];
               int idx = 0, mul = 1;
               bool ok = true;
@@ -2288,7 +2312,7 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
             }
             __syncthreads();
           }
-          for (int r = tid; r < nt; r += kBlock) tp_score[(size_t)j * Tmax + r] = tp_score[(size_t)j * Tmax + r] + tp_best[r];
+          for (int r = tid; r < nt; r += kThreads) tp_score[(size_t)j * Tmax + r] = tp_score[(size_t)j * Tmax + r] + tp_best[r];
         }
         __syncthreads();
       }
@@ -2353,13 +2377,17 @@ __global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBa
 }
 
 size_t phase_lds_bytes(const PhaseLds& l) {
+  const int nwv = l.nwv > 4 ? l.nwv : 4;
+  const int rw0 = l.nmax > 2048 ? 64 : 32;
+  const int rw = rw0 > nwv * 8 ? rw0 : nwv * 8;
   size_t b = (size_t)l.nmax * 8 * 2;       // bestF, bestP
   b += (size_t)l.nmax * 2 * 5;             // cl + 4 lists
   b += (size_t)l.nmax * 2 * (l.items_lds ? 5 : 1);  // rowbuf[4] (the LDS part of the candidate-edge list), dlist
   b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4;  // multiw (padded to 8 bytes)
-  b += (size_t)2 * 4 * (l.nmax > 2048 ? 64 : 32) * 8;    // rmask, rolenz
+  b += (size_t)2 * 4 * rw * 8;             // rmask, rolenz (and the per-wave pending lists that re-use them)
   b += (size_t)l.nmax;                     // role
   if (l.stage_row) b += (size_t)l.nmax * 4;  // wrow
+  if (nwv > 4) b += 8 + (size_t)nwv * l.nmax * 4;  // per-wave scratch of the wide forms (S4a keys, S5-init neighbour lists)
   {  // the threading DP re-uses the region: tuple-code map (u16) + one marginal table (u64 + u32)
     size_t codes = 1, marg = 1;
     for (int i = 0; i < l.ploidy; i++) { marg = codes; codes *= (size_t)(2 * l.ploidy); }
@@ -2369,23 +2397,36 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   return (b + 15) & ~(size_t)15;
 }
 
-int phase_max_blocks_per_cu(const PhaseLds& l) {
-  int nb = 0;
-  int nb32 = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_phase_t<false>, kBlock, phase_lds_bytes(l)) != hipSuccess) return 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb32, k_phase_t<true>, kBlock, phase_lds_bytes(l)) != hipSuccess) return 1;
+namespace {
+template <int NWV>
+int max_blocks(const PhaseLds& l) {
+  int nb = 0, nb32 = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_phase_t<false, NWV>, NWV * 64, phase_lds_bytes(l)) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb32, k_phase_t<true, NWV>, NWV * 64, phase_lds_bytes(l)) != hipSuccess) return 1;
   if (nb32 < nb) nb = nb32;
   return nb < 1 ? 1 : nb;
+}
+template <int NWV>
+void launch_nwv(const DeviceBatch& db, const SlotWorkspace& ws, const PhaseLds& l, const int* queue, int C, int* ctl, int* deferred, int slots,
+                hipStream_t stream) {
+  // narrow induced costs first; the chains it had to defer (none in the BASELINE configurations 1-3 and 5) go
+  // through the wide-cost instance, whose workgroups find an empty list otherwise
+  hipLaunchKernelGGL((k_phase_t<true, NWV>), dim3(slots), dim3(NWV * 64), phase_lds_bytes(l), stream, db, ws, l, queue, C, (const int*)nullptr, ctl,
+                     deferred, ctl + 2);
+  hipLaunchKernelGGL((k_phase_t<false, NWV>), dim3(slots), dim3(NWV * 64), phase_lds_bytes(l), stream, db, ws, l, (const int*)deferred, 0,
+                     (const int*)(ctl + 2), ctl + 1, (int*)nullptr, (int*)nullptr);
+}
+}  // namespace
+
+int phase_max_blocks_per_cu(const PhaseLds& l) {
+  return l.nwv == 16 ? max_blocks<16>(l) : l.nwv == 8 ? max_blocks<8>(l) : max_blocks<4>(l);
 }
 
 void launch_phase(const DeviceBatch& db, const SlotWorkspace& ws, const PhaseLds& l, const int* queue, int C, int* ctl, int* deferred,
                   int slots, hipStream_t stream) {
-  // narrow induced costs first; the chains it had to defer (none in the BASELINE configurations 1-3 and 5) go
-  // through the wide instance, whose workgroups find an empty list otherwise
-  hipLaunchKernelGGL(k_phase_t<true>, dim3(slots), dim3(kBlock), phase_lds_bytes(l), stream, db, ws, l, queue, C, (const int*)nullptr, ctl, deferred,
-                     ctl + 2);
-  hipLaunchKernelGGL(k_phase_t<false>, dim3(slots), dim3(kBlock), phase_lds_bytes(l), stream, db, ws, l, (const int*)deferred, 0,
-                     (const int*)(ctl + 2), ctl + 1, (int*)nullptr, (int*)nullptr);
+  if (l.nwv == 16) launch_nwv<16>(db, ws, l, queue, C, ctl, deferred, slots, stream);
+  else if (l.nwv == 8) launch_nwv<8>(db, ws, l, queue, C, ctl, deferred, slots, stream);
+  else launch_nwv<4>(db, ws, l, queue, C, ctl, deferred, slots, stream);
 }
 
 }  // namespace ahk

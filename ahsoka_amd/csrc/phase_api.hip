@@ -154,6 +154,7 @@ extern "C" void ahsoka_default_params(ahsoka_phase_params* prm) {
   prm->max_slots = 0;
   prm->symmetry_opt = 0;  // HaploThreader(ploidy, 32.0, 8.0, false, 0), :320
   prm->row_limit = 0;
+  prm->wave_mode = 0;
 }
 
 extern "C" int ahsoka_abi_version(void) { return AHSOKA_ABI_VERSION; }
@@ -252,6 +253,7 @@ static int upload_impl(const ahsoka_chain_batch* in, const ahsoka_phase_params* 
                        ahsoka_device_batch** hp) {
   if (!in || !prm || !handle) return AHSOKA_E_ARG;
   if (prm->ploidy < 2 || prm->ploidy > kMaxPloidy || prm->min_overlap < 0 || prm->max_slots < 0) return AHSOKA_E_ARG;
+  if (prm->wave_mode != 0 && prm->wave_mode != 4 && prm->wave_mode != 8 && prm->wave_mode != 16) return AHSOKA_E_ARG;
   // (threading scores must be non-negative: the device argmin orders them by their bit patterns)
   if (!(prm->switch_cost >= 0.0) || !(prm->affine_switch_cost >= 0.0)) return AHSOKA_E_ARG;
   // the threader's symmetryOptimization / rowLimit exist at the boundary so that it mirrors :320
@@ -623,7 +625,7 @@ static int build_classes(ahsoka_device_batch* h) {
   // largest readset whose per-read LDS arrays fit a workgroup of this device
   int ncap = 64;
   for (int v = 64; v <= ((kMaxReads + 63) & ~63); v += 64) {
-    PhaseLds t{v, 0, h->prm.ploidy, 0, 0};
+    PhaseLds t{v, 0, h->prm.ploidy, 0, 0, 4};
     if (phase_lds_bytes(t) <= h->lds_per_block) ncap = v;
   }
   bool demoted = false;
@@ -658,10 +660,11 @@ static int build_classes(ahsoka_device_batch* h) {
     if (status[c] == AHSOKA_ST_PHASED) members[(size_t)class_of(nfin[c])].push_back(c);
   long long Tmax = 1;
   for (int i = 0; i < h->prm.ploidy; i++) Tmax *= 2 * h->prm.ploidy;
-  int per_cu_cap = 5;  // launch bounds of k_phase: five workgroups of four waves per CU
+  int per_cu_cap4 = 5;  // launch bounds of k_phase: five workgroups of four waves per CU
 #ifdef AHK_DIAG
-  if (const char* e = std::getenv("AHSOKA_WG_PER_CU")) per_cu_cap = std::max(1, std::atoi(e));  // diagnostic builds only
+  if (const char* e = std::getenv("AHSOKA_WG_PER_CU")) per_cu_cap4 = std::max(1, std::atoi(e));  // diagnostic builds only
 #endif
+  int per_cu_cap = per_cu_cap4;
   for (size_t k = 0; k < caps.size(); k++) {
     if (members[k].empty()) continue;
     PhaseClass pc;
@@ -670,6 +673,22 @@ static int build_classes(ahsoka_device_batch* h) {
     pc.pl.nmax = pc.nmax;
     pc.pl.stop_after = h->stop_after;
     pc.pl.ploidy = h->prm.ploidy;
+    // Wavefronts per workgroup.  A class whose chains all get a CU (or half of one) to themselves is bound by
+    // the latency of its largest chain, not by throughput: it takes the 16- (8-) wave form of the kernel, whose
+    // trip-count-bound passes shorten with the lane count.  Everything else takes the four-wave form, five
+    // workgroups per CU.  prm.wave_mode forces a form (tests; results do not depend on it).
+    pc.pl.nwv = 4;
+    if (h->prm.wave_mode != 0) pc.pl.nwv = h->prm.wave_mode;
+    else if (pc.count <= h->n_cu) pc.pl.nwv = 16;
+    else if (pc.count <= 2 * h->n_cu) pc.pl.nwv = 8;
+    {  // (a wide form whose per-wave scratch does not fit the LDS even without the extras below: the next narrower one)
+      PhaseLds base = pc.pl;
+      base.items_lds = 0;
+      base.stage_row = 0;
+      while (base.nwv > 4 && phase_lds_bytes(base) > h->lds_per_block) base.nwv /= 2;
+      pc.pl.nwv = base.nwv;
+    }
+    per_cu_cap = pc.pl.nwv == 16 ? 1 : pc.pl.nwv == 8 ? 2 : per_cu_cap4;
     for (int c : members[k]) pc.Pmax = std::max(pc.Pmax, h->meta[(size_t)c].B);
     // LDS extras of S5 by occupancy: the LDS part of the candidate-edge list (8 B per read) is
     // dropped where that buys a workgroup per CU; the staged weight row (4 B per read) is added
@@ -694,8 +713,8 @@ static int build_classes(ahsoka_device_batch* h) {
       if (phase_lds_bytes(with) <= h->lds_per_block && std::min(phase_max_blocks_per_cu(with), per_cu_cap) >= per_cu) pc.pl = with;
     }
 #ifdef AHK_DIAG
-    std::fprintf(stderr, "ahsoka: class nmax=%d chains=%d workgroups/CU=%d lds=%zu B items_lds=%d stage_row=%d\n", pc.nmax, pc.count, per_cu,
-                 phase_lds_bytes(pc.pl), pc.pl.items_lds, pc.pl.stage_row);
+    std::fprintf(stderr, "ahsoka: class nmax=%d chains=%d waves=%d workgroups/CU=%d lds=%zu B items_lds=%d stage_row=%d\n", pc.nmax, pc.count,
+                 pc.pl.nwv, per_cu, phase_lds_bytes(pc.pl), pc.pl.items_lds, pc.pl.stage_row);
 #endif
     pc.slots = std::max(1, std::min(pc.count, h->n_cu * per_cu));
     if (h->prm.max_slots > 0) pc.slots = std::min(pc.slots, h->prm.max_slots);

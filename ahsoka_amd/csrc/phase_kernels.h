@@ -7,7 +7,7 @@
 // that can move their HBM traffic or time: a committed counter summary (profiles/*_pmc_hbm.json)
 // carries the tag it was taken with, and bench.py reports `roofline.traffic` only from a summary
 // of the SAME revision (never a counter of one kernel version next to a time of another).
-#define AHK_KERNEL_REV "r03.1"
+#define AHK_KERNEL_REV "r03.2"
 
 namespace ahk {
 
@@ -139,6 +139,7 @@ struct PhaseLds {
   int stage_row;   // 1: room for the staged weight row (4 B per read) -- set when it does not cost a workgroup per CU
   int items_lds;   // 1: the first 2*nmax candidate edges of an iteration are listed in LDS (8 B per read), 0: all in HBM
                    //    -- dropped when that buys a workgroup per CU
+  int nwv;         // wavefronts per workgroup: 4 (throughput form; 0 means 4) or 8 / 16 (latency forms, k_phase.hip)
 };
 struct ReadsetLds2 {  // k_readset_lds: the sizes ONE chain's LDS layout follows from
   int maxBitWords;   // ceil(N/64) * R: u64 words of all alignment bitsets

@@ -140,6 +140,10 @@ typedef struct ahsoka_phase_params {
                                  anything else is rejected with AHSOKA_E_UNSUPPORTED      */
   int32_t row_limit;          /* HaploThreader's rowLimit: reference literal 0 = unlimited
                                  (:320).  Only 0 is implemented (AHSOKA_E_UNSUPPORTED)    */
+  int32_t wave_mode;          /* 0 = automatic.  4 / 8 / 16 force that many wavefronts per workgroup
+                                 in the cluster-editing kernel (4: throughput form, five chains
+                                 per CU; 8 / 16: latency forms for chains that have a CU to
+                                 themselves).  A performance knob; results do not depend on it */
 } ahsoka_phase_params;
 
 /*

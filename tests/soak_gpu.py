@@ -25,7 +25,7 @@ def random_case(k, off, rng):
     b = random_batch(50000 + 1000 * off + k, dup_paths=(k % 5 == 0), n_chains=int(rng.choice([1, 4, 9])),
                      max_bubbles=int(rng.choice([6, 14, 40])), max_reads=int(rng.choice([30, 120, 400])))
     prm = capi.default_params(want_stages=1, min_mapq=int(rng.choice([90, 93, 95])), compaction_mode=int(k % 2),
-                              max_slots=int(rng.choice([0, 0, 1, 3])))
+                              max_slots=int(rng.choice([0, 0, 1, 3])), wave_mode=int(rng.choice([0, 4, 8, 16])))
     g, _ = _compare(b, prm)
     if k % 7 == 0:  # the device-list entry: shards on the same GPU, merged result identical
         m = capi.phase_batch_multi(b, [0, 0, 0], prm)
@@ -44,7 +44,7 @@ def shape_case(k, off, rng, max_reads=1600):
     nc = 3 if nr > 800 else 6
     b = capi.synth_batch(n_chains=nc, n_bubbles=nb, n_reads=nr, ploidy=ploidy, seed=7000 + 1000 * off + k,
                          mean_span=float(rng.choice([3.0, 7.0, 15.0])), allele_err=float(rng.choice([0.0, 0.02, 0.15])))
-    _compare(b, capi.default_params(ploidy=ploidy, want_stages=1, max_slots=int(rng.choice([0, 2])),
+    _compare(b, capi.default_params(ploidy=ploidy, want_stages=1, max_slots=int(rng.choice([0, 2])), wave_mode=int(rng.choice([0, 4, 8, 16])),
                                     switch_cost=float(rng.choice([32.0, 5.0, 0.5])), affine_switch_cost=float(rng.choice([8.0, 0.0, 1.25]))))
     return nc, nb, nr, ploidy
 

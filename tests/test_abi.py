@@ -65,7 +65,7 @@ def test_parameter_validation_precedes_the_device():
     b = capi.synth_batch(**capi.CONFIGS["c1"])
     h = C.c_void_p()
     for bad in (dict(ploidy=1), dict(ploidy=9), dict(min_overlap=-1), dict(max_slots=-1), dict(switch_cost=-1.0),
-                dict(affine_switch_cost=float("nan"))):
+                dict(affine_switch_cost=float("nan")), dict(wave_mode=5), dict(wave_mode=32)):
         prm = capi.default_params(**bad)
         assert L.ahsoka_batch_upload(b.ptr(), C.byref(prm), C.byref(h)) == capi.E_ARG, bad
     # s1_order must be a permutation of the chain's bubble ids

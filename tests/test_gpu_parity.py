@@ -47,9 +47,12 @@ def test_c1_all_stages():
 @pytest.mark.parametrize("seed", [1, 2, 3])
 @pytest.mark.parametrize("shape", [(6, 3, 12), (4, 20, 200), (3, 70, 300), (2, 130, 260)])
 def test_small_shapes_all_stages(seed, shape):
+    """(every form of the cluster-editing kernel: 4, 8 and 16 wavefronts per workgroup -- the automatic choice
+    for so few chains would be 16 only)"""
     nc, nb, nr = shape
     b = capi.synth_batch(n_chains=nc, n_bubbles=nb, n_reads=nr, seed=seed)
-    _compare(b, capi.default_params(want_stages=1))
+    for wm in (4, 8, 16):
+        _compare(b, capi.default_params(want_stages=1, wave_mode=wm))
 
 
 def test_compaction_mode_1():
@@ -219,7 +222,8 @@ def test_slot_reuse_c5_all_stages():
     cfg = dict(capi.CONFIGS["c5"])
     cfg["n_chains"] = 1500
     b = capi.synth_batch(**cfg)
-    _compare(b, capi.default_params(want_stages=1, max_slots=16), n_threads=16)
+    _compare(b, capi.default_params(want_stages=1, max_slots=16, wave_mode=4), n_threads=16)
+    _compare(b, capi.default_params(max_slots=16), stages=False, n_threads=16)  # (automatic: wide forms for the small classes)
 
 
 def test_slot_reuse_large_then_small_chain():
@@ -230,15 +234,18 @@ def test_slot_reuse_large_then_small_chain():
     small = capi.synth_batch(n_chains=3, n_bubbles=30, n_reads=560, seed=77).arrays()
     mid = capi.synth_batch(n_chains=2, n_bubbles=40, n_reads=760, seed=78).arrays()
     b = _concat([small, big, mid])
-    g, o = _compare(b, capi.default_params(want_stages=1, max_slots=1), n_threads=8)
+    g, o = _compare(b, capi.default_params(want_stages=1, max_slots=1, wave_mode=4), n_threads=8)
     assert g.n_reads.max() > 1.6 * g.n_reads.min() and g.n_reads.min() > g.n_reads.max() // 2  # one size class
+    for wm in (8, 16):
+        _compare(b, capi.default_params(want_stages=1, max_slots=1, wave_mode=wm), n_threads=8)
 
 
 def test_slot_reuse_ploidy4():
     """64 tetraploid chains through 8 slots: the threading tables (up to 4096 tuples per
     position) are slot state too"""
     b = capi.synth_batch(n_chains=64, n_bubbles=12, n_reads=240, ploidy=4, seed=0xA450CA04)
-    _compare(b, capi.default_params(want_stages=1, ploidy=4, max_slots=8), n_threads=16)
+    _compare(b, capi.default_params(want_stages=1, ploidy=4, max_slots=8, wave_mode=4), n_threads=16)
+    _compare(b, capi.default_params(want_stages=1, ploidy=4, max_slots=8, wave_mode=16), n_threads=16)
 
 
 def _concat(parts):
@@ -440,7 +447,7 @@ def test_random_irregular_batches(seed):
     from random_batches import random_batch
 
     b = random_batch(1000 + seed)
-    _compare(b, capi.default_params(want_stages=1, min_mapq=93 if seed % 2 else 90))
+    _compare(b, capi.default_params(want_stages=1, min_mapq=93 if seed % 2 else 90, wave_mode=(0, 4, 8)[seed % 3]))
 
 
 @pytest.mark.parametrize("over", [
@@ -550,6 +557,7 @@ def test_other_ploidies(ploidy):
     """ploidy is a parameter of the ABI (reference literal 2, quirk Q17); tuples = (2p)^p"""
     b = capi.synth_batch(n_chains=4, n_bubbles=10, n_reads=150, ploidy=ploidy, seed=900 + ploidy)
     _compare(b, capi.default_params(want_stages=1, ploidy=ploidy))
+    _compare(b, capi.default_params(want_stages=1, ploidy=ploidy, wave_mode=4))
     # reference literal genotype {0:1,1:1} with ploidy > 2: nothing conforms, all tuples are used
     a = b.arrays()
     a.pop("genotype")
@@ -594,7 +602,8 @@ def test_wide_induced_costs_instance():
     long spans give ~1170 final reads whose largest row sum is 2^31.7: this chain takes the wide
     instance (every other test and configuration takes the narrow one), two of them through one slot."""
     b = capi.synth_batch(n_chains=2, n_bubbles=16, n_reads=1800, ploidy=2, seed=12, mean_span=15.0, allele_err=0.0)
-    g, o = _compare(b, capi.default_params(want_stages=1, max_slots=1))
+    g, o = _compare(b, capi.default_params(want_stages=1, max_slots=1, wave_mode=4))
+    _compare(b, capi.default_params(want_stages=1, max_slots=1, wave_mode=16))
     assert (g.status == capi.ST_PHASED).all()
     n = int(o.n_reads[0])
     w = np.asarray(o.stages["score_q"][: n * n], dtype=np.int64).reshape(n, n)
