@@ -673,13 +673,15 @@ static int build_classes(ahsoka_device_batch* h) {
     pc.pl.nmax = pc.nmax;
     pc.pl.stop_after = h->stop_after;
     pc.pl.ploidy = h->prm.ploidy;
-    // Wavefronts per workgroup.  A class whose chains all get a CU (or half of one) to themselves is bound by
-    // the latency of its largest chain, not by throughput: it takes the 16- (8-) wave form of the kernel, whose
-    // trip-count-bound passes shorten with the lane count.  Everything else takes the four-wave form, five
-    // workgroups per CU.  prm.wave_mode forces a form (tests; results do not depend on it).
+    // Wavefronts per workgroup.  A class whose chains all get half a CU to themselves is bound by the latency of
+    // its largest chain, not by throughput: it takes the 8-wave form of the kernel, whose trip-count-bound passes
+    // shorten with the lane count (measured, tools/wave_modes.sh: config 5's k_phase 62.9 -> 51.5 ms, 256 chains
+    // of config 3 125.8 -> 103.7 ms, 512 chains 134.8 -> 117.2 ms; the 16-wave form is no faster than four waves:
+    // its barriers and the sequential single-read separations outweigh the shorter passes).  Everything else
+    // takes the four-wave form, five workgroups per CU.  prm.wave_mode forces a form (tests and experiments;
+    // results do not depend on it).
     pc.pl.nwv = 4;
     if (h->prm.wave_mode != 0) pc.pl.nwv = h->prm.wave_mode;
-    else if (pc.count <= h->n_cu) pc.pl.nwv = 16;
     else if (pc.count <= 2 * h->n_cu) pc.pl.nwv = 8;
     {  // (a wide form whose per-wave scratch does not fit the LDS even without the extras below: the next narrower one)
       PhaseLds base = pc.pl;

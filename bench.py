@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 
 class Shard:
     """This rank's share of one global synthetic workload, resident in HBM."""
 
-    def __init__(self, capi, shard, cfg, total_chains, rank, world, device_index, max_slots=0):
+    def __init__(self, capi, shard, cfg, total_chains, rank, world, device_index, max_slots=0, wave_mode=0):
         self.capi, self.shardmod = capi, shard
         self.cfg = dict(cfg)
         self.cfg["n_chains"] = total_chains
@@ -67,7 +67,7 @@ class Shard:
             self.batch = capi.synth_select(mine, **self.cfg)
         self.synth_s = time.time() - t0
         self.bubble_off = self.batch.arrays()["bubble_off"]
-        self.prm = capi.default_params(ploidy=self.ploidy, device=device_index, max_slots=max_slots)
+        self.prm = capi.default_params(ploidy=self.ploidy, device=device_index, max_slots=max_slots, wave_mode=wave_mode)
         t0 = time.time()
         self.dev = capi.DeviceBatch(self.batch, self.prm)
         self.upload_s = time.time() - t0
@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
                     help="N > 1: strong = the fixed workload split over the ranks (default), weak = that workload per rank")
     ap.add_argument("--max-slots", type=int, default=0, help="ahsoka_phase_params.max_slots (experiments only)")
+    ap.add_argument("--wave-mode", type=int, default=0, help="ahsoka_phase_params.wave_mode: 0 automatic, 4 / 8 / 16 wavefronts per workgroup (experiments only)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="chains timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
@@ -130,7 +131,7 @@ def main():
 
     def run(total_chains, steps, warmup):
         """-> dict of measurements of `steps` timed steps on the workload of total_chains chains"""
-        sh = Shard(capi, shard, cfg, total_chains, rank, world, local_rank, args.max_slots)
+        sh = Shard(capi, shard, cfg, total_chains, rank, world, local_rank, args.max_slots, args.wave_mode)
         pad = None
         if world > 1:
             pad = torch.full((sh.max_block,), -1, dtype=torch.int32, device=coll_device)
