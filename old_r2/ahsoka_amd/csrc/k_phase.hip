@@ -127,32 +127,24 @@ __device__ __forceinline__ int icp_term(int p, int q) {
 }
 #endif
 // Packed key of an edge (a,b), a < b, with induced cost val >= 0:
-//   (val+1) << 25 | stale << 24 | (4095-a) << 12 | (4095-b)
+//   (val+1) << 23 | stale << 22 | (2047-a) << 11 | (2047-b)
 // One unsigned 64-bit max picks the largest value and, among equal values, the
 // lexicographically smallest pair -- the heuristic's global tie rule.  Within one
 // row that is also "smallest other end", so the per-row maxima are kept in this
 // very form and the argmax is a plain max over them.  The stale bit marks a row
 // maximum that is only an upper bound (its edge went down or died): among equal
 // values a stale key wins the max, which is exactly "some stale row ties the
-// maximum -> rescan before deciding".  The ends are 12-bit fields (n <= 4096 = kMaxReads), which
-// leaves 39 bits for val+1: exact for every narrow (32-bit induced cost) chain; the wide instance
-// checks its chain's bound 2 * max row sum of |W| < 2^39 - 1 once, after S4b, and reports a chain
-// beyond it AHSOKA_ST_UNSUPPORTED (weights are clamped to 2^30: more than 256 neighbours at the clamp).
-// 0 = no live edge.
-constexpr int kKeyEndBits = 12;
-constexpr unsigned int kKeyEndMax = (1u << kKeyEndBits) - 1u;            // 4095
-constexpr int kKeyValShift = 2 * kKeyEndBits + 1;                         // 25
-constexpr unsigned long long kStale = 1ull << (2 * kKeyEndBits);          // bit 24
-constexpr unsigned long long kPairMask = (1ull << (2 * kKeyEndBits)) - 1ull;
-constexpr long long kKeyValMax = (1ll << (64 - kKeyValShift)) - 2;       // largest val a key can carry
-static_assert(kMaxReads <= (1 << kKeyEndBits), "packed edge keys hold 12-bit read indices");
+// maximum -> rescan before deciding".  val+1 <= 2047 * 2^30 < 2^41 (weights are
+// clamped to 2^30, n <= 2048).  0 = no live edge.
+constexpr unsigned long long kStale = 1ull << 22;
+constexpr unsigned long long kPairMask = (1ull << 22) - 1ull;
 __device__ __forceinline__ unsigned long long mkkey(long long val, int r, int c) {
   const unsigned int a = r < c ? r : c, b = r < c ? c : r;
-  return ((unsigned long long)(val + 1) << kKeyValShift) | (unsigned long long)(((kKeyEndMax - a) << kKeyEndBits) | (kKeyEndMax - b));
+  return ((unsigned long long)(val + 1) << 23) | (unsigned long long)(((2047u - a) << 11) | (2047u - b));
 }
-__device__ __forceinline__ long long key_val(unsigned long long k) { return (long long)(k >> kKeyValShift) - 1; }
-__device__ __forceinline__ int key_a(unsigned long long k) { return (int)kKeyEndMax - (int)((k >> kKeyEndBits) & (unsigned long long)kKeyEndMax); }
-__device__ __forceinline__ int key_b(unsigned long long k) { return (int)kKeyEndMax - (int)(k & (unsigned long long)kKeyEndMax); }
+__device__ __forceinline__ long long key_val(unsigned long long k) { return (long long)(k >> 23) - 1; }
+__device__ __forceinline__ int key_a(unsigned long long k) { return 2047 - (int)((k >> 11) & 2047ull); }
+__device__ __forceinline__ int key_b(unsigned long long k) { return 2047 - (int)(k & 2047ull); }
 // the other end of the edge in key k, seen from its end r
 __device__ __forceinline__ int key_other(unsigned long long k, int r) {
   const int a = key_a(k), b = key_b(k);
@@ -386,11 +378,11 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
 }
 
 // rows dlist[0..nd): wave wv takes pairs of rows
-template <class IcT, int NWV>
+template <class IcT>
 __device__ __forceinline__ void rescan_list(const unsigned short* dlist, int nd, int wv, int lane, int n, int nw,
                                             const unsigned long long* __restrict__ LV, const IcT* __restrict__ IC,
                                             unsigned long long* bestF, unsigned long long* bestP) {
-  for (int di = 2 * wv; di < nd; di += 2 * NWV) {
+  for (int di = 2 * wv; di < nd; di += 8) {
     // (the rows are wave-uniform: as scalars, their address arithmetic runs on the scalar unit)
     const int r0 = __builtin_amdgcn_readfirstlane((int)dlist[di]);
     const int r1 = di + 1 < nd ? __builtin_amdgcn_readfirstlane((int)dlist[di + 1]) : -1;
@@ -405,17 +397,6 @@ __device__ __forceinline__ void rescan_list(const unsigned short* dlist, int nd,
       }
     }
   }
-}
-
-// S4a sort key of a scored pair: (Hamming rate d/o as floor(d * 2^20 / o), overlap o) -- the exact order by
-// rate, ties by overlap.  o <= 4095 covered positions (kMaxBubbles) take 12 bits; the rate of a pair that
-// differs everywhere (d == o: 2^20, the only value above 2^20 - 2^20/o) is stored as 2^20 - 2, which keeps
-// its place in the order, still gives d back as ceil(rate * o / 2^20), and leaves 0xFFFFFFFF free as the
-// "not scored" mark.  (oracle.cpp: the same function)
-__device__ __forceinline__ unsigned int rate_key(unsigned int d, unsigned int o) {
-  unsigned int rate = (d << 20) / o;
-  if (rate > (1u << 20) - 2u) rate = (1u << 20) - 2u;
-  return (rate << 12) | o;
 }
 
 struct GreaterCnt {  // cmp() of the reference, :699-701: coverage descending
@@ -596,10 +577,6 @@ __device__ __forceinline__ void tri_seg_wide(const int* __restrict__ Wm, int n, 
 #ifndef AHK_WAVES_PER_SIMD
 #define AHK_WAVES_PER_SIMD 5
 #endif
-#ifndef AHK_INIT_ROWS
-#define AHK_INIT_ROWS 4
-#endif
-constexpr int kInitRows = AHK_INIT_ROWS;  // consecutive rows a wave of S5-init prices together (they share every third-edge gather)
 // IC32: induced costs as 2 x uint32 (IcPair32).  Exact for a chain whose induced costs provably stay
 // below 2^32: they are sums of non-negative terms, and every term of icf(a,b) / icp(a,b) is at most
 // |W[b][x]| where that is finite and |W[a][x]| where it is not (never both infinite on a live edge),
@@ -608,20 +585,11 @@ constexpr int kInitRows = AHK_INIT_ROWS;  // consecutive rows a wave of S5-init 
 // kernel is bound by those (+10 % at config 3).  A chain that fails the test right after S4b is
 // put on the `deferred` list and left to the 64-bit instance, launched behind this one with that
 // list as its queue (Cdev = its length, on the device).
-// NWV: wavefronts per workgroup.  4 is the throughput form (five workgroups per CU, 1280 chains in
-// flight); 8 and 16 are the LATENCY forms for a size class whose chains all have a CU (or half of
-// one) to themselves -- config 5's largest chains, a batch of few chains, a shard at N = 8: the
-// trip-count-bound passes of an iteration (candidate listing, edge pass, rescans, heavy chunks,
-// S5 init, S4) shorten with the lane count, the strictly sequential parts (argmax, the two
-// dependent round trips of a single-read separation) do not.  Results do not depend on NWV.
-// RW: words of the per-word role tables (a compile-time stride: as a run-time value it cost 3 % at config 3):
-// 32 for classes of at most 2048 reads, 64 beyond; the wide forms need NWV * 8 for their pending lists.
-template <bool IC32, int NWV, int RW>
-__global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k_phase_t(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
+template <bool IC32>
+__global__ __launch_bounds__(kBlock, AHK_WAVES_PER_SIMD) void k_phase_t(DeviceBatch db, SlotWorkspace ws, PhaseLds lds, const int* __restrict__ queue,
                                                        int C, const int* __restrict__ Cdev, int* __restrict__ qhead,
                                                        int* __restrict__ deferred, int* __restrict__ ndeferred) {
   using IcT = typename std::conditional<IC32, IcPair32, IcPair>::type;
-  constexpr int kThreads = NWV * 64;
   if (Cdev) C = *Cdev;
   extern __shared__ __align__(16) unsigned long long smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -647,23 +615,16 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
   unsigned short* rowbuf = listFb + nmax;                 // [4][nmax] as u16 = the first 2*nmax entries of the candidate-edge list (absent if !lds.items_lds)
   unsigned short* dlist = rowbuf + (lds.items_lds ? 4 * (size_t)nmax : 0);  // [nmax] rows whose maximum must be rescanned
   unsigned int* multiw = (unsigned int*)(dlist + nmax);   // [nmax/32] bit per read: its clique has > 1 member
-  // RW = words of a bitmap row the class can have, 32 (n <= 2048) or 64: sizes the per-word role tables
-  // (and, in the wide forms, gives room for the per-wave pending lists that re-use the tables: 128 u32 per wave)
-  static_assert(RW >= NWV * 8 && (RW == 32 || RW == 64 || RW == 128), "role tables");
-  unsigned long long* rmask = (unsigned long long*)(multiw + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][RW] role masks per 64-column word
-  unsigned long long* rolenz = rmask + 4 * RW;             // [4][RW] OR of the members' nz-rows
-  unsigned char* role = (unsigned char*)(rolenz + 4 * RW);  // [nmax]
+  unsigned long long* rmask = (unsigned long long*)(multiw + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][32] role masks per 64-column word
+  unsigned long long* rolenz = rmask + 4 * 32;             // [4][32] OR of the members' nz-rows
+  unsigned char* role = (unsigned char*)(rolenz + 4 * 32);  // [nmax]
   int* wrow = (int*)(role + nmax);                         // [nmax] weights of a single read's row (see "staged row")
-  // per-wave scratch of S4a (key buffer, u32) and S5 init (neighbour list, u16): the four-wave form
-  // re-uses bestF/bestP and the role lists, which hold exactly four such buffers; the wide forms
-  // have a region of their own (one workgroup or two per CU: the LDS is there)
-  unsigned int* wscr = NWV > 4 ? (unsigned int*)(((size_t)(wrow + (lds.stage_row ? nmax : 0)) + 7) & ~(size_t)7) : nullptr;  // [NWV][nmax]
   __shared__ int s_chain, s_cnt[4], s_nd, s_items, s_nh, s_nslow;
-  __shared__ unsigned short s_pref[4][64];
+  __shared__ unsigned short s_pref[4][32];
 #ifdef AHK_TIMING
   __shared__ int s_chg;
 #endif
-  __shared__ unsigned long long s_rk[2 * NWV < 16 ? 16 : 2 * NWV];
+  __shared__ unsigned long long s_rk[16];
 #ifdef AHK_FTRACE
   __shared__ unsigned long long s_ft[4][16];
   long long ftl = 0;
@@ -703,8 +664,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
 
     // ================= S4a: per-read local Hamming-rate estimates ==========
     {
-      unsigned int* keybuf = (NWV > 4 ? wscr : (unsigned int*)bestF) + (size_t)wv * nmax;  // (4 waves x nmax u32 = 16*nmax bytes = bestF + bestP)
-      for (int i = wv; i < n; i += NWV) {
+      unsigned int* keybuf = (unsigned int*)bestF + (size_t)wv * nmax;  // 4 waves x nmax u32 = 16*nmax bytes
+      for (int i = wv; i < n; i += 4) {
         int cnt = 0;
         long long dall = 0, oall = 0;
         for (int j = lane; j < n; j += 64) {
@@ -713,7 +674,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
             int o, d;
             pair_overlap(cx, i, j, &o, &d);
             if (o >= db.min_overlap && o > 0) {
-              key = rate_key((unsigned)d, (unsigned)o);
+              key = ((((unsigned)d << 20) / (unsigned)o) << 10) | (unsigned)o;
               cnt++;
               dall += d;
               oall += o;
@@ -729,7 +690,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           int msel = cnt / ploidy;
           if (msel == 0) msel = 1;
           // smallest key T with #(key <= T) >= msel
-          unsigned int lo = 0, hi = 0xFFFFFFFEu;
+          unsigned int lo = 0, hi = 0x7FFFFFFFu;
           while (lo < hi) {
             const unsigned int mid = lo + ((hi - lo) >> 1);
             int cle = 0;
@@ -744,7 +705,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           for (int j = lane; j < n; j += 64) {
             const unsigned int key = keybuf[j];
             if (key < T) {
-              const unsigned int o = key & 4095u, rate = key >> 12;
+              const unsigned int o = key & 1023u, rate = key >> 10;
               const unsigned long long dd = ((unsigned long long)rate * o + ((1u << 20) - 1)) >> 20;
               cl_lt++;
               ds += (long long)dd;
@@ -754,7 +715,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           cl_lt = wave_sum_i(cl_lt);
           ds = wave_sum_ll(ds);
           os = wave_sum_ll(os);
-          const unsigned int oT = T & 4095u, rT = T >> 12;
+          const unsigned int oT = T & 1023u, rT = T >> 10;
           const long long dT = (long long)(((unsigned long long)rT * oT + ((1u << 20) - 1)) >> 20);
           ds += (long long)(msel - cl_lt) * dT;
           os += (long long)(msel - cl_lt) * (long long)oT;
@@ -776,7 +737,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
 
     // ================= S4b: similarity matrix W ============================
     long long smax = 0;  // (this wave's rows) largest row sum of |W|: decides whether 32-bit induced costs are exact
-    for (int i = wv; i < n; i += NWV) {
+    for (int i = wv; i < n; i += 4) {
       const double si = rates[i], fi = rates[n + i];
       long long srow = 0;
       for (int j = lane; j < n; j += 64) {
@@ -797,32 +758,24 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         if (m.dump0 >= 0) db.score_dump[m.dump0 + (size_t)i * n + j] = q;
         srow += q < 0 ? -(long long)q : (long long)q;
       }
-      srow = wave_sum_i64(srow);
-      smax = srow > smax ? srow : smax;
+      if (IC32) {
+        srow = wave_sum_i64(srow);
+        smax = srow > smax ? srow : smax;
+      }
     }
-    if (lane == 0) s_rk[wv] = (unsigned long long)smax;
-    for (int u = tid; u < n; u += kThreads) {
+    if (IC32 && lane == 0) s_rk[wv] = (unsigned long long)smax;
+    for (int u = tid; u < n; u += kBlock) {
       cl[u] = (unsigned short)u;
       role[u] = ROLE_NONE;
     }
     __syncthreads();
-    {
+    if (IC32) {
       // every induced cost of this chain is at most S(a) + S(b) <= 2 * max row sum: below 2^32, or the chain goes to
-      // the wide instance (uniform: every wave reads the same four values); the wide instance in turn needs the
-      // value to fit the 39-bit field of the packed edge keys
+      // the wide instance (uniform: every wave reads the same four values)
       unsigned long long sm = s_rk[0];
-      for (int k = 1; k < NWV; k++) sm = s_rk[k] > sm ? s_rk[k] : sm;
-      if (IC32) {
-        if (2ull * sm >= (1ull << 32)) {
-          if (tid == 0) deferred[atomicAdd(ndeferred, 1)] = c;
-          continue;
-        }
-      } else if (2ull * sm > (unsigned long long)kKeyValMax) {
-        if (tid == 0) {
-          db.status[c] = AHSOKA_ST_UNSUPPORTED;
-          db.nclusters[c] = 0;
-          db.niter[c] = 0;
-        }
+      for (int k = 1; k < 4; k++) sm = s_rk[k] > sm ? s_rk[k] : sm;
+      if (2ull * sm >= (1ull << 32)) {
+        if (tid == 0) deferred[atomicAdd(ndeferred, 1)] = c;
         continue;
       }
     }
@@ -839,72 +792,49 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
     // iff its bit is set, and IC holds garbage for dead pairs.
     const int nw = (n + 63) >> 6;
     // words per row rounded up to a power of two (>= 8): lane layout of the row passes
-    const int nwp_log = nw <= 8 ? 3 : nw <= 16 ? 4 : nw <= 32 ? 5 : 6;
+    const int nwp_log = nw <= 8 ? 3 : nw <= 16 ? 4 : 5;
     const int nwp = 1 << nwp_log;
     const int RP = 64 >> nwp_log;  // rows a wave handles at once
-    // Each unordered pair {a,b} is computed once, by the wave of its lower end a (lanes = the
-    // neighbours b > a), and stored for both orientations; the row maxima are folded in with LDS
-    // atomics.  A wave takes kInitRows CONSECUTIVE rows at a time: reads are sorted by first
-    // position, so neighbouring rows have nearly the same neighbours, and over the union of their
-    // neighbour lists every third-edge gather W[w][b] (one row segment of W per w: 3-4 HBM lines)
-    // is made ONCE and priced against all rows of the group -- a non-neighbour w of a row has
-    // weight 0 there and both of its terms vanish, so the union needs no per-row masks.  One row
-    // per wave re-read each chain's 1.4 MB of weights ~30 times (a fifth of the kernel's HBM
-    // traffic, round 2); four rows per group make a quarter of those gathers and drop the
-    // v_readlane of the row weight from three of four terms.
-    for (int u = tid; u < n; u += kThreads) { bestF[u] = 0ull; bestP[u] = 0ull; }
+    // Each unordered pair {a,b} is computed once, by the wave of its lower end a
+    // (lanes = the neighbours b > a), and stored for both orientations; the row
+    // maxima are folded in with LDS atomics.  Halving the pairs halves the HBM
+    // lines of the W[w][b] gathers: this phase runs at ~80 % of the achievable
+    // HBM rate (the 190 neighbour rows of a read do not fit any cache share).
+    for (int u = tid; u < n; u += kBlock) { bestF[u] = 0ull; bestP[u] = 0ull; }
     __syncthreads();
     {
-      // induced costs of a narrow (IC32) chain are < 2^32 and sums of non-negative terms: 32-bit
-      // unsigned accumulators are exact there
-      using AccT = typename std::conditional<IC32, unsigned int, long long>::type;
-      unsigned short* nbr = NWV > 4 ? (unsigned short*)(wscr + (size_t)wv * nmax)
-                                    : listA + (size_t)wv * nmax;   // union of the group's neighbours, ascending (the role lists are free here)
-      for (int a0 = wv * kInitRows; a0 < n; a0 += NWV * kInitRows) {
-        const int R = n - a0 < kInitRows ? n - a0 : kInitRows;
+      unsigned short* nbr = listA + (size_t)wv * nmax;   // all neighbours of a, ascending (the role lists are free here)
+      for (int a = wv; a < n; a += 4) {
         int deg = 0, dhi = 0;
         for (int w0 = 0; w0 < n; w0 += 64) {
           const int w = w0 + lane;
-          bool nzu = false;
-#pragma unroll
-          for (int r = 0; r < kInitRows; r++) {
-            const bool nz = r < R && w < n && WM_AT((unsigned)((a0 + r) * n + w)) != 0;
-            const unsigned long long mk = __ballot(nz);
-            if (r < R && lane == 0) {
-              LV_AT((unsigned)((a0 + r) * nw + (w0 >> 6))) = mk;
-              NZ_AT((unsigned)((a0 + r) * nw + (w0 >> 6))) = mk;
-            }
-            nzu = nzu || nz;
-          }
-          const unsigned long long mu = __ballot(nzu);
-          const unsigned long long mh = __ballot(nzu && w > a0);
-          if (nzu) nbr[deg + __popcll(mu & ((1ull << lane) - 1ull))] = (unsigned short)w;
-          deg += __popcll(mu);
+          const bool nz = w < n && WM_AT((unsigned)(a * n + w)) != 0;
+          const unsigned long long mk = __ballot(nz);
+
+          const unsigned long long mh = __ballot(nz && w > a);
+          if (nz) nbr[deg + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)w;
+          deg += __popcll(mk);
           dhi += __popcll(mh);
+          if (lane == 0) {
+            LV_AT((unsigned)(a * nw + (w0 >> 6))) = mk;
+            NZ_AT((unsigned)(a * nw + (w0 >> 6))) = mk;
+          }
         }
-        // lanes = the union's members b > a0 (the tail of the ascending list): a pair (a_r, b) of the
-        // group is this wave's iff b > a_r and W[a_r][b] != 0.  The rows' own weights W[a_r][w] are
-        // wave-uniform: 64 of them per row come with ONE load (lane = list index) and are handed out
-        // with v_readlane; padding entries read as weight 0 (both terms vanish): nothing is predicated.
-        const unsigned short* nhi = nbr + (deg - dhi);
+        // lanes = the neighbours b > a.  The row's own weights W[a][w] are wave-uniform:
+        // 64 of them are fetched with ONE load (lane = neighbour index) and handed out
+        // with v_readlane -- as scalar operands -- instead of 64 uniform loads; padding
+        // neighbours read as weight 0 (both terms vanish), so nothing is predicated.
+        const unsigned short* nhi = nbr + (deg - dhi);  // the neighbours b > a: the tail of the ascending list
         for (int i0 = 0; i0 < dhi; i0 += 64) {
           const int i = i0 + lane;
           const bool act = i < dhi;
-          const int b = act ? (int)nhi[i] : a0;
-          int wab[kInitRows];
-          AccT f[kInitRows], p[kInitRows];
-#pragma unroll
-          for (int r = 0; r < kInitRows; r++) {
-            wab[r] = r < R ? WM_AT((unsigned)((a0 + r) * n + b)) : 0;  // (a,a) is 0
-            f[r] = (AccT)(wab[r] > 0 ? wab[r] : 0);
-            p[r] = (AccT)(wab[r] < 0 ? -wab[r] : 0);
-          }
+          const int b = act ? (int)nhi[i] : a;
+          const int wab = WM_AT((unsigned)(a * n + b));  // (a,a) is 0
+          long long f = wab > 0 ? wab : 0, p = wab < 0 ? -(long long)wab : 0;
           for (int k0 = 0; k0 < deg; k0 += 64) {
             const int kk = k0 + lane;
-            const int nb_l = kk < deg ? (int)nbr[kk] : a0;
-            int wa_l[kInitRows];
-#pragma unroll
-            for (int r = 0; r < kInitRows; r++) wa_l[r] = (r < R && kk < deg) ? WM_AT((unsigned)((a0 + r) * n + nb_l)) : 0;
+            const int nb_l = kk < deg ? (int)nbr[kk] : a;
+            const int wa_l = WM_AT((unsigned)(a * n + nb_l));
             const int cnt = deg - k0 < 64 ? deg - k0 : 64;
             for (int c0 = 0; c0 < cnt; c0 += 8) {
               int wb[8];
@@ -915,35 +845,28 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
               }
 #pragma unroll
               for (int c = 0; c < 8; c++) {
-#pragma unroll
-                for (int r = 0; r < kInitRows; r++) {
-                  const int wa = __builtin_amdgcn_readlane(wa_l[r], c0 + c);
-                  f[r] += (AccT)icf_term(wa, wb[c]);
-                  p[r] += (AccT)icp_term(wa, wb[c]);
-                }
+                const int wa = __builtin_amdgcn_readlane(wa_l, c0 + c);
+                f += icf_term(wa, wb[c]);
+                p += icp_term(wa, wb[c]);
               }
             }
           }
-#pragma unroll
-          for (int r = 0; r < kInitRows; r++) {
-            const int a = a0 + r;
-            if (act && r < R && b > a && wab[r] != 0) {
-              IcT v;
-              v.f = f[r];
-              v.p = p[r];
-              IC_AT((unsigned)(a * n + b)) = v;
-              IC_AT((unsigned)(b * n + a)) = v;
-              const unsigned long long kf = mkkey((long long)f[r], a, b), kp = mkkey((long long)p[r], a, b);
-              atomicMax(&bestF[a], kf);
-              atomicMax(&bestP[a], kp);
-              atomicMax(&bestF[b], kf);
-              atomicMax(&bestP[b], kp);
-            }
+          if (act) {
+            IcT v;
+            v.f = f;
+            v.p = p;
+            IC_AT((unsigned)(a * n + b)) = v;
+            IC_AT((unsigned)(b * n + a)) = v;
+            const unsigned long long kf = mkkey(f, a, b), kp = mkkey(p, a, b);
+            atomicMax(&bestF[a], kf);
+            atomicMax(&bestP[a], kp);
+            atomicMax(&bestF[b], kf);
+            atomicMax(&bestP[b], kp);
           }
         }
       }
     }
-    for (int u = tid; u < (n + 31) / 32; u += kThreads) multiw[u] = 0;
+    for (int u = tid; u < (n + 31) / 32; u += kBlock) multiw[u] = 0;
     if (tid < 4) s_cnt[tid] = 0;
     if (tid == 0) { s_nd = 0; s_items = 0; s_nh = 0; s_nslow = 0; }
     __syncthreads();
@@ -983,7 +906,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         // heuristic's tie rule is one 64-bit max over them, and its stale bit says
         // whether a stale bound ties the maximum
         unsigned long long gF = 0ull, gP = 0ull;
-        for (int u = tid; u < n; u += kThreads) {
+        for (int u = tid; u < n; u += kBlock) {
           const unsigned long long k1 = bestF[u], k2 = bestP[u];
           gF = k1 > gF ? k1 : gF;
           gP = k2 > gP ? k2 : gP;
@@ -992,15 +915,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         gF = wave_max_u64(gF);
         gP = wave_max_u64(gP);
         if (lane == 0) {
-          s_rk[wv] = gF; s_rk[NWV + wv] = gP;
+          s_rk[wv] = gF; s_rk[4 + wv] = gP;
         }
         AHK_F(1);
         __syncthreads();
         AHK_F(2);
 #pragma unroll
-        for (int k = 0; k < NWV; k++) {
+        for (int k = 0; k < 4; k++) {
           gF = s_rk[k] > gF ? s_rk[k] : gF;
-          gP = s_rk[NWV + k] > gP ? s_rk[NWV + k] : gP;
+          gP = s_rk[4 + k] > gP ? s_rk[4 + k] : gP;
         }
         gF = readlane_u64(gF, 0);  // (every lane holds the same two keys: make them scalars)
         gP = readlane_u64(gP, 0);
@@ -1012,14 +935,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         AHK_T(0);
         if (!need) break;  // uniform
         // collect the stale rows whose bound ties a maximum, rescan them exactly
-        for (int u = tid; u < n; u += kThreads) {
+        for (int u = tid; u < n; u += kBlock) {
           const unsigned long long k1 = bestF[u], k2 = bestP[u];
-          if (((k1 & kStale) && (k1 >> kKeyValShift) == (gF >> kKeyValShift)) || ((k2 & kStale) && (k2 >> kKeyValShift) == (gP >> kKeyValShift)))
+          if (((k1 & kStale) && (k1 >> 23) == (gF >> 23)) || ((k2 & kStale) && (k2 >> 23) == (gP >> 23)))
             dlist[atomicAdd(&s_nd, 1)] = (unsigned short)u;
         }
         __syncthreads();
         {
-          rescan_list<IcT, NWV>(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
+          rescan_list(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
         }
         __syncthreads();
 #ifdef AHK_TIMING
@@ -1046,8 +969,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
       // trips per iteration instead of about ten.
       AHK_F(3);
       if (!merge && !(((multiw[eu >> 5] >> (eu & 31)) | (multiw[ev >> 5] >> (ev & 31))) & 1u)) {
-        constexpr int NSUB = NWV / 2;  // waves per row
-        const int half = wv / NSUB, sub = wv % NSUB;
+        const int half = wv >> 1, sub = wv & 1;
         const int x = half ? ev : eu, w = half ? eu : ev;
         unsigned long long lvn = 0ull, nzo = 0ull;
         if (lane < nw) {
@@ -1062,19 +984,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         unsigned long long todo = __ballot(lvn != 0ull);
         unsigned long long kF = 0ull, kP = 0ull;
         AHK_F(4);
-        // this wave takes the live words whose rank is sub modulo NSUB (four waves: even / odd rank), kFastBatch per trip
+        // this wave takes the live words of even (sub 0) / odd (sub 1) rank, kFastBatch per trip
         while (todo != 0ull) {
           int lw[kFastBatch];
 #pragma unroll
           for (int c = 0; c < kFastBatch; c++) {
-#pragma unroll
-            for (int q = 0; q < NSUB - 1; q++)
-              if (q < sub && todo != 0ull) todo &= todo - 1ull;
+            if (sub && todo != 0ull) todo &= todo - 1ull;
             lw[c] = todo != 0ull ? __builtin_ctzll(todo) : -1;
             if (todo != 0ull) todo &= todo - 1ull;
-#pragma unroll
-            for (int q = 0; q < NSUB - 1; q++)
-              if (q >= sub && todo != 0ull) todo &= todo - 1ull;
+            if (!sub && todo != 0ull) todo &= todo - 1ull;
           }
           IcT icv[kFastBatch];
           int wb[kFastBatch];
@@ -1121,21 +1039,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         AHK_F(5);
         kF = wave_max_u64(kF);
         kP = wave_max_u64(kP);
-        if (lane == 0) { s_rk[wv] = kF; s_rk[NWV + wv] = kP; }
+        if (lane == 0) { s_rk[wv] = kF; s_rk[4 + wv] = kP; }
         AHK_F(6);
         __syncthreads();
         AHK_F(7);
         if (tid < 2) {
           const int xr = tid ? ev : eu;
-          unsigned long long a1 = 0ull, b1 = 0ull;  // (the row's waves: NSUB partial maxima each)
-#pragma unroll
-          for (int q = 0; q < NSUB; q++) {
-            const unsigned long long a2 = s_rk[NSUB * tid + q], b2 = s_rk[NWV + NSUB * tid + q];
-            a1 = a2 > a1 ? a2 : a1;
-            b1 = b2 > b1 ? b2 : b1;
-          }
-          bestF[xr] = a1;
-          bestP[xr] = b1;
+          const unsigned long long a1 = s_rk[2 * tid], a2 = s_rk[2 * tid + 1], b1 = s_rk[4 + 2 * tid], b2 = s_rk[4 + 2 * tid + 1];
+          bestF[xr] = a1 > a2 ? a1 : a2;
+          bestP[xr] = b1 > b2 ? b1 : b2;
           WM_AT((unsigned)(xr * n + (tid ? eu : ev))) = W_FORB;  // every wave has read the old weight by now
         }
         __syncthreads();
@@ -1162,13 +1074,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
       const int rs = !lds.stage_row ? -1
                                     : __builtin_amdgcn_readfirstlane(!((multiw[eu >> 5] >> (eu & 31)) & 1u) ? eu : (!((multiw[ev >> 5] >> (ev & 31)) & 1u) ? ev : -1));
       if (rs >= 0)
-        for (int z = tid; z < n; z += kThreads) wrow[z] = WM_AT((unsigned)(rs * n + z));
+        for (int z = tid; z < n; z += kBlock) wrow[z] = WM_AT((unsigned)(rs * n + z));
 
       // ---- P2: roles, member lists and per-word role masks --------------------
       // (s_cnt was zeroed before the last barrier).  rmask[R][k] has bit c set iff
       // column 64k+c plays role R: the row passes below work on whole 64-column
       // words with these masks instead of looking at single columns.
-      for (int z0 = 0; z0 < nw * 64; z0 += kThreads) {
+      for (int z0 = 0; z0 < nw * 64; z0 += kBlock) {
         const int z = z0 + tid;
         int r = ROLE_NONE;
         if (z < n) {
@@ -1186,10 +1098,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         const unsigned long long m3 = __ballot(r == ROLE_FA), m4 = __ballot(r == ROLE_FB);
         const int k = (z0 >> 6) + wv;
         if (lane == 0 && k < nw) {
-          rmask[0 * RW + k] = m1;
-          rmask[1 * RW + k] = m2;
-          rmask[2 * RW + k] = m3;
-          rmask[3 * RW + k] = m4;
+          rmask[0 * 32 + k] = m1;
+          rmask[1 * 32 + k] = m2;
+          rmask[2 * 32 + k] = m3;
+          rmask[3 * 32 + k] = m4;
         }
       }
       __syncthreads();
@@ -1197,19 +1109,19 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
       // popcounts of role R, then every member finds its slot by a popcount below its bit
       // (consecutive list entries are neighbouring columns: the row accesses W[x][w] over a
       // list touch few lines, and the heavy-edge pass relies on the order)
-      if (wv < 4) {  // (four roles: waves 0..3)
-        const unsigned long long mw = lane < nw ? rmask[wv * RW + lane] : 0ull;
+      {
+        const unsigned long long mw = lane < nw ? rmask[wv * 32 + lane] : 0ull;
         const int pc = __popcll(mw);
         const int incl = wave_scan_i(pc);
-        s_pref[wv][lane] = (unsigned short)(incl - pc);
+        if (lane < 32) s_pref[wv][lane] = (unsigned short)(incl - pc);
         if (lane == 63) s_cnt[wv] = incl;
       }
       __syncthreads();
-      for (int z = tid; z < n; z += kThreads) {
+      for (int z = tid; z < n; z += kBlock) {
         const int r = role[z];
         if (r == ROLE_NONE) continue;
         const int k = z >> 6;
-        const int slot = (int)s_pref[r - 1][k] + __popcll(rmask[(r - 1) * RW + k] & ((1ull << (z & 63)) - 1ull));
+        const int slot = (int)s_pref[r - 1][k] + __popcll(rmask[(r - 1) * 32 + k] & ((1ull << (z & 63)) - 1ull));
         unsigned short* Lz = r == ROLE_A ? listA : r == ROLE_B ? listB : r == ROLE_FA ? listFa : listFb;
         Lz[slot] = (unsigned short)z;
       }
@@ -1231,7 +1143,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
       // ---- P2b: per role, the OR of the nz-rows of its members (wave R <-> role R):
       // "some member w of the role has W[w][b] != 0".  One pass per iteration,
       // shared by every row of P3a; lists longer than 32 are not filtered.
-      if (wv < 4) {
+      {
         const unsigned short* Lr = wv == 0 ? listA : wv == 1 ? listB : wv == 2 ? listFa : listFb;
         const int nr = wv == 0 ? nA : wv == 1 ? nB : wv == 2 ? nFa : nFb;
         unsigned long long acc = 0ull;
@@ -1246,7 +1158,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
             for (int c = 0; c < 8; c++) acc |= t[c];
           }
         }
-        if (lane < RW) rolenz[wv * RW + lane] = acc;
+        if (lane < 32) rolenz[wv * 32 + lane] = acc;
       }
       __syncthreads();
       AHK_T(2);
@@ -1274,8 +1186,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         // this lane's word of every role mask / neighbour mask: read from LDS once
         unsigned long long mA = 0ull, mB = 0ull, mFa = 0ull, mFb = 0ull, oA = 0ull, oB = 0ull, oFa = 0ull, oFb = 0ull;
         if (wordok) {
-          mA = rmask[kw]; mB = rmask[RW + kw]; mFa = rmask[2 * RW + kw]; mFb = rmask[3 * RW + kw];
-          oA = rolenz[kw]; oB = rolenz[RW + kw]; oFa = rolenz[2 * RW + kw]; oFb = rolenz[3 * RW + kw];
+          mA = rmask[kw]; mB = rmask[32 + kw]; mFa = rmask[64 + kw]; mFb = rmask[96 + kw];
+          oA = rolenz[kw]; oB = rolenz[32 + kw]; oFa = rolenz[64 + kw]; oFb = rolenz[96 + kw];
         }
         const unsigned long long Tm = mA | mB | mFa | mFb;
         const unsigned long long segmask = (nwp == 64 ? ~0ull : ((1ull << nwp) - 1ull)) << (slot << nwp_log);
@@ -1289,17 +1201,17 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         // the bitmap words of pass k+1 are requested before pass k is processed: with
         // hundreds of rewritten rows (a large clique) every pass would otherwise wait
         // for its own HBM round trip
-        int x_nx = row_of(wv * RP + slot);  // (a workgroup pass handles NWV * RP rows)
+        int x_nx = row_of(wv * RP + slot);
         unsigned long long lv_nx = 0ull, nz_nx = 0ull;
         if (x_nx >= 0 && wordok) {
           lv_nx = LV_AT((unsigned)(x_nx * nw + kw));
           nz_nx = NZ_AT((unsigned)(x_nx * nw + kw));
         }
-        for (int xi0 = wv * RP; xi0 < nT; xi0 += NWV * RP) {
+        for (int xi0 = wv * RP; xi0 < nT; xi0 += 4 * RP) {
           const int xi = xi0 + slot;
           const int x = x_nx;
           const unsigned long long lvw = lv_nx, nzw = nz_nx;
-          x_nx = row_of(xi + NWV * RP);
+          x_nx = row_of(xi + 4 * RP);
           lv_nx = 0ull;
           nz_nx = 0ull;
           if (x_nx >= 0 && wordok) {
@@ -1650,14 +1562,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           auto fetch = [&](const int i) -> unsigned int { return i < M ? (i < cap ? items_lds[i] : items_glb[i - cap]) : 0u; };
           unsigned int q[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) q[u] = fetch(tid + u * kThreads);
-          for (int i0 = 0; i0 < M; i0 += 4 * kThreads) {
+          for (int u = 0; u < 4; u++) q[u] = fetch(tid + u * kBlock);
+          for (int i0 = 0; i0 < M; i0 += 4 * kBlock) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-              const int ib = i0 + u * kThreads;
+              const int ib = i0 + u * kBlock;
               if (ib < M) {  // uniform
                 const unsigned int it = q[u];
-                q[u] = fetch(ib + tid + 4 * kThreads);
+                q[u] = fetch(ib + tid + 4 * kBlock);
                 classify(it, ib + tid < M);
               }
             }
@@ -1691,9 +1603,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           };
           unsigned int it_nx = 0u;
           if (tid < cnt0 + cnt1) it_nx = fetchB(tid);
-          for (int i = tid; i < cnt0 + cnt1; i += kThreads) {
+          for (int i = tid; i < cnt0 + cnt1; i += kBlock) {
             const unsigned int it = it_nx;
-            if (i + kThreads < cnt0 + cnt1) it_nx = fetchB(i + kThreads);
+            if (i + kBlock < cnt0 + cnt1) it_nx = fetchB(i + kBlock);
             plain_item(it, (int)(it >> 28), (int)((it >> 24) & 7u));
           }
         }
@@ -1720,7 +1632,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           unsigned long long* hacc = rmask;  // [2 * kHeavyCap]: rmask and rolenz are dead after P3a
           for (int r0 = 0; r0 < nh; r0 += kHeavyCap) {
             const int nr = nh - r0 < kHeavyCap ? nh - r0 : kHeavyCap;
-            for (int k = tid; k < 2 * nr; k += kThreads) hacc[k] = 0ull;
+            for (int k = tid; k < 2 * nr; k += kBlock) hacc[k] = 0ull;
             __syncthreads();
             // chunks per edge: the largest count over the heavy roles spans the grid
             int chmax = 0;
@@ -1734,7 +1646,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
               if (((heavy >> ROLE_FB) & 1u) && cFb > chmax) chmax = cFb;
             }
             const int V = nr * chmax;
-            for (int v = tid; v < V; v += kThreads) {
+            for (int v = tid; v < V; v += kBlock) {
               const int c = v / nr, hh = v - c * nr;
               const unsigned int it = hl[r0 + hh];
               const int rx = (int)(it >> 28);
@@ -1759,7 +1671,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
               if (dp != 0) atomicAdd(&hacc[2 * hh + 1], (unsigned long long)dp);
             }
             __syncthreads();
-            for (int hh0 = 0; hh0 < nr; hh0 += kThreads) {
+            for (int hh0 = 0; hh0 < nr; hh0 += kBlock) {
               const int hh = hh0 + tid;
               long long df = 0, dp = 0;
               if (hh < nr) {
@@ -1885,7 +1797,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         {
           const int ny = nB + nFb;
           const int np1 = nA * ny, np2 = nB * nFa;
-          for (int i = tid; i < np1 + np2; i += kThreads) {
+          for (int i = tid; i < np1 + np2; i += kBlock) {
             int x, y, N;
             if (i < np1) {
               const int xi = i / ny, yi = i - xi * ny;
@@ -1904,12 +1816,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           }
         }
         if (merge) {
-          for (int yi = tid; yi < nB; yi += kThreads) {
+          for (int yi = tid; yi < nB; yi += kBlock) {
             const int y = listB[yi];
             cl[y] = (unsigned short)cu;
             atomicOr(&multiw[y >> 5], 1u << (y & 31));
           }
-          for (int xi = tid; xi < nA; xi += kThreads) {
+          for (int xi = tid; xi < nA; xi += kBlock) {
             const int x = listA[xi];
             atomicOr(&multiw[x >> 5], 1u << (x & 31));
           }
@@ -1918,7 +1830,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         if (tid == 0) { s_items = 0; s_nh = 0; s_nslow = 0; }
         AHK_T(6);  // (diagnostic build: weight rewrites vs rescans)
         // rows whose maximum died: exact rescan now (they would tie the next argmax anyway)
-        rescan_list<IcT, NWV>(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
+        rescan_list(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
         AHK_T(7);
       }
       __syncthreads();
@@ -1993,9 +1905,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
     // ---- clusters: ordered by smallest member ------------------------------
     // (bestF is free now: reuse as scratch)
     unsigned int* scratch = (unsigned int*)bestF;  // [4*nmax] u32 available
-    for (int u = tid; u < n; u += kThreads) scratch[u] = 0xFFFFFFFFu;
+    for (int u = tid; u < n; u += kBlock) scratch[u] = 0xFFFFFFFFu;
     __syncthreads();
-    for (int u = tid; u < n; u += kThreads) atomicMin(&scratch[cl[u]], (unsigned)u);
+    for (int u = tid; u < n; u += kBlock) atomicMin(&scratch[cl[u]], (unsigned)u);
     __syncthreads();
     if (wv == 0) {
       int base = 0;
@@ -2010,13 +1922,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
     }
     __syncthreads();
     const int K = __builtin_amdgcn_readfirstlane(s_back);
-    for (int u = tid; u < n; u += kThreads) {
+    for (int u = tid; u < n; u += kBlock) {
       const int kc = (int)scratch[nmax + scratch[cl[u]]];
       db.fr_cluster[m.fr0 + u] = kc;
       scratch[2 * (size_t)nmax + u] = (unsigned)kc;
     }
     __syncthreads();
-    for (int u = tid; u < n; u += kThreads) cl[u] = (unsigned short)scratch[2 * (size_t)nmax + u];
+    for (int u = tid; u < n; u += kBlock) cl[u] = (unsigned short)scratch[2 * (size_t)nmax + u];
     if (tid == 0) {
       db.nclusters[c] = K;
       db.niter[c] = iters;
@@ -2027,9 +1939,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
     const int P = cx.P;
     const int nA_all = 1 << cx.planes;
     {
-      unsigned int* hist = (unsigned int*)bestF + (size_t)(wv & 3) * nmax;  // per wave, [K]
-      unsigned int* sb = sortbuf + (size_t)(wv & 3) * ws.nmax;
-      for (int j = wv; j < P && wv < 4; j += 4) {  // (per-wave histogram and sort buffer: four waves)
+      unsigned int* hist = (unsigned int*)bestF + (size_t)wv * nmax;  // per wave, [K]
+      unsigned int* sb = sortbuf + (size_t)wv * ws.nmax;
+      for (int j = wv; j < P; j += 4) {
         for (int k = lane; k < K; k += 64) hist[k] = 0;
         const int wj = j >> 6, bj = j & 63;
         int tot = 0;
@@ -2051,7 +1963,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         }
         // sort(): by coverage descending, std::sort from ascending-id order (:707-727)
         __threadfence_block();  // sb is global memory shared between the lanes of this wave
-        if (lane < 8) s_asc[wv & 3][lane] = lane < M ? (int)sb[lane] : 0;
+        if (lane < 8) s_asc[wv][lane] = lane < M ? (int)sb[lane] : 0;
         if (lane == 0) gnu_sort(sb, M, GreaterCnt());
         __threadfence_block();
         // get_pos_to_clusters_map cut-off (:763-772)
@@ -2099,7 +2011,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           } else {
             // reference compaction (:379-402): coverage = i-th cluster present at the
             // position in ascending id; consensus = i-th covMap cluster in ascending id
-            tp_cov[(size_t)j * 8 + lane] = (double)((unsigned)s_asc[wv & 3][lane] >> 16) / (double)tot;
+            tp_cov[(size_t)j * 8 + lane] = (double)((unsigned)s_asc[wv][lane] >> 16) / (double)tot;
           }
         }
         if (db.compaction_mode == 0) {
@@ -2123,7 +2035,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
     {
       const long long Tmax = ws.Tmax;
       {
-        for (int j = wv; j < P; j += NWV) {  // one wave per position
+        for (int j = wv; j < P; j += 4) {  // one wave per position
           const int k = tp_k[j];
           int T = 1;
           for (int i = 0; i < ploidy; i++) T *= k;
@@ -2170,7 +2082,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
       for (int j = 0; j < P; j++) {
         const int k = tp_k[j], nt = tp_ntup[j];
         const int kp = j > 0 ? tp_k[j - 1] : 1, ntp = j > 0 ? tp_ntup[j - 1] : 0;
-        for (int r = tid; r < nt; r += kThreads) {
+        for (int r = tid; r < nt; r += kBlock) {
           int t[kMaxPloidy], g[kMaxPloidy];
           int rem = tp_tuples[(size_t)j * Tmax + r];
           for (int i = ploidy - 1; i >= 0; i--) { t[i] = rem % k; rem /= k; }
@@ -2220,9 +2132,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           unsigned int* tabQ = (unsigned int*)(tabS + pw[ploidy - 1]);                      // [kp^(p-1)] lowest index reaching it
           const int* tup_prev = tp_tuples + (size_t)(j - 1) * Tmax;
           const double* sc_prev = tp_score + (size_t)(j - 1) * Tmax;
-          for (int cidx2 = tid; cidx2 < ncode; cidx2 += kThreads) idxmap[cidx2] = 0xffffu;
+          for (int cidx2 = tid; cidx2 < ncode; cidx2 += kBlock) idxmap[cidx2] = 0xffffu;
           __syncthreads();
-          for (int q = tid; q < ntp; q += kThreads) idxmap[tup_prev[q]] = (unsigned short)q;
+          for (int q = tid; q < ntp; q += kBlock) idxmap[tup_prev[q]] = (unsigned short)q;
           __syncthreads();
           // slot i of tuple r lives in cluster gcid[j][t_i]: its index among the previous
           // position's clusters (or -1) -- per thread, eight clusters at most
@@ -2243,7 +2155,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
             return v;
           };
           // S = all slots: exact predecessor with the same clusters
-          for (int r = tid; r < nt; r += kThreads) {
+          for (int r = tid; r < nt; r += kBlock) {
             int rem = tp_tuples[(size_t)j * Tmax + r];
             int code = 0;
             bool ok = true;
@@ -2269,10 +2181,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           for (int S = 0; S < nsub; S++) {
             const int nS = __popc((unsigned)S), sw = ploidy - nS;
             const int nent = pw[nS];
-            for (int e = tid; e < nent; e += kThreads) { tabS[e] = ~0ull; tabQ[e] = 0xffffffffu; }
+            for (int e = tid; e < nent; e += kBlock) { tabS[e] = ~0ull; tabQ[e] = 0xffffffffu; }
             __syncthreads();
             for (int pass = 0; pass < 2; pass++) {
-              for (int q = tid; q < ntp; q += kThreads) {
+              for (int q = tid; q < ntp; q += kBlock) {
                 int rem = tup_prev[q];
                 int idx = 0, mul = 1;
                 for (int i = ploidy - 1; i >= 0; i--) {
@@ -2287,7 +2199,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
               __syncthreads();
             }
             const double add = db.switch_cost * (double)sw + (sw > 0 ? db.affine_cost : 0.0);
-            for (int r = tid; r < nt; r += kThreads) {
+            for (int r = tid; r < nt; r += kBlock) {
               int rem = tp_tuples[(size_t)j * Tmax + r];
               int idx = 0, mul = 1;
               bool ok = true;
@@ -2314,7 +2226,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
             }
             __syncthreads();
           }
-          for (int r = tid; r < nt; r += kThreads) tp_score[(size_t)j * Tmax + r] = tp_score[(size_t)j * Tmax + r] + tp_best[r];
+          for (int r = tid; r < nt; r += kBlock) tp_score[(size_t)j * Tmax + r] = tp_score[(size_t)j * Tmax + r] + tp_best[r];
         }
         __syncthreads();
       }
@@ -2379,17 +2291,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
 }
 
 size_t phase_lds_bytes(const PhaseLds& l) {
-  const int nwv = l.nwv > 4 ? l.nwv : 4;
-  const int rw0 = l.nmax > 2048 ? 64 : 32;
-  const int rw = rw0 > nwv * 8 ? rw0 : nwv * 8;
   size_t b = (size_t)l.nmax * 8 * 2;       // bestF, bestP
   b += (size_t)l.nmax * 2 * 5;             // cl + 4 lists
   b += (size_t)l.nmax * 2 * (l.items_lds ? 5 : 1);  // rowbuf[4] (the LDS part of the candidate-edge list), dlist
   b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4;  // multiw (padded to 8 bytes)
-  b += (size_t)2 * 4 * rw * 8;             // rmask, rolenz (and the per-wave pending lists that re-use them)
+  b += 2 * 4 * 32 * 8;                                   // rmask, rolenz
   b += (size_t)l.nmax;                     // role
   if (l.stage_row) b += (size_t)l.nmax * 4;  // wrow
-  if (nwv > 4) b += 8 + (size_t)nwv * l.nmax * 4;  // per-wave scratch of the wide forms (S4a keys, S5-init neighbour lists)
   {  // the threading DP re-uses the region: tuple-code map (u16) + one marginal table (u64 + u32)
     size_t codes = 1, marg = 1;
     for (int i = 0; i < l.ploidy; i++) { marg = codes; codes *= (size_t)(2 * l.ploidy); }
@@ -2399,40 +2307,23 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   return (b + 15) & ~(size_t)15;
 }
 
-namespace {
-template <int NWV, int RW>
-int max_blocks(const PhaseLds& l) {
-  int nb = 0, nb32 = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_phase_t<false, NWV, RW>, NWV * 64, phase_lds_bytes(l)) != hipSuccess) return 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb32, k_phase_t<true, NWV, RW>, NWV * 64, phase_lds_bytes(l)) != hipSuccess) return 1;
+int phase_max_blocks_per_cu(const PhaseLds& l) {
+  int nb = 0;
+  int nb32 = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_phase_t<false>, kBlock, phase_lds_bytes(l)) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb32, k_phase_t<true>, kBlock, phase_lds_bytes(l)) != hipSuccess) return 1;
   if (nb32 < nb) nb = nb32;
   return nb < 1 ? 1 : nb;
-}
-template <int NWV, int RW>
-void launch_nwv(const DeviceBatch& db, const SlotWorkspace& ws, const PhaseLds& l, const int* queue, int C, int* ctl, int* deferred, int slots,
-                hipStream_t stream) {
-  // narrow induced costs first; the chains it had to defer (none in the BASELINE configurations 1-3 and 5) go
-  // through the wide-cost instance, whose workgroups find an empty list otherwise
-  hipLaunchKernelGGL((k_phase_t<true, NWV, RW>), dim3(slots), dim3(NWV * 64), phase_lds_bytes(l), stream, db, ws, l, queue, C, (const int*)nullptr, ctl,
-                     deferred, ctl + 2);
-  hipLaunchKernelGGL((k_phase_t<false, NWV, RW>), dim3(slots), dim3(NWV * 64), phase_lds_bytes(l), stream, db, ws, l, (const int*)deferred, 0,
-                     (const int*)(ctl + 2), ctl + 1, (int*)nullptr, (int*)nullptr);
-}
-}  // namespace
-
-// (the instances: four waves with 32- or 64-word role tables, eight waves, sixteen waves)
-int phase_max_blocks_per_cu(const PhaseLds& l) {
-  if (l.nwv == 16) return max_blocks<16, 128>(l);
-  if (l.nwv == 8) return max_blocks<8, 64>(l);
-  return l.nmax > 2048 ? max_blocks<4, 64>(l) : max_blocks<4, 32>(l);
 }
 
 void launch_phase(const DeviceBatch& db, const SlotWorkspace& ws, const PhaseLds& l, const int* queue, int C, int* ctl, int* deferred,
                   int slots, hipStream_t stream) {
-  if (l.nwv == 16) launch_nwv<16, 128>(db, ws, l, queue, C, ctl, deferred, slots, stream);
-  else if (l.nwv == 8) launch_nwv<8, 64>(db, ws, l, queue, C, ctl, deferred, slots, stream);
-  else if (l.nmax > 2048) launch_nwv<4, 64>(db, ws, l, queue, C, ctl, deferred, slots, stream);
-  else launch_nwv<4, 32>(db, ws, l, queue, C, ctl, deferred, slots, stream);
+  // narrow induced costs first; the chains it had to defer (none in the BASELINE configurations 1-3 and 5) go
+  // through the wide instance, whose workgroups find an empty list otherwise
+  hipLaunchKernelGGL(k_phase_t<true>, dim3(slots), dim3(kBlock), phase_lds_bytes(l), stream, db, ws, l, queue, C, (const int*)nullptr, ctl, deferred,
+                     ctl + 2);
+  hipLaunchKernelGGL(k_phase_t<false>, dim3(slots), dim3(kBlock), phase_lds_bytes(l), stream, db, ws, l, (const int*)deferred, 0,
+                     (const int*)(ctl + 2), ctl + 1, (int*)nullptr, (int*)nullptr);
 }
 
 }  // namespace ahk

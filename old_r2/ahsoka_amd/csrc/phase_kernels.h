@@ -3,26 +3,17 @@
 #pragma once
 #include <stdint.h>
 
-// Revision tag of the kernels' memory behaviour.  Bumped with every change of k_phase / k_readset
-// that can move their HBM traffic or time: a committed counter summary (profiles/*_pmc_hbm.json)
-// carries the tag it was taken with, and bench.py reports `roofline.traffic` only from a summary
-// of the SAME revision (never a counter of one kernel version next to a time of another).
-#define AHK_KERNEL_REV "r03.3"
-
 namespace ahk {
 
 // compiled-in device limits (a chain beyond them comes back AHSOKA_ST_UNSUPPORTED)
-constexpr int kMaxBubbles = 4095;   // positions are 12-bit fields of sort keys (k_readset creation keys, S4a rate keys)
-constexpr int kMaxNodes = 8192;     // chain-local node indices: k_readset's node window covers 2048 of them around an alignment
-constexpr int kMaxNames = 8192;     // distinct read names per chain (k_readset LDS: 16 B per name)
-constexpr int kMaxAlns = 65535;     // alignments per chain (16-bit field of the creation keys)
-constexpr int kMaxReads = 4096;     // reads in the final readset (k_phase: 12-bit ends of the packed edge keys, 64-word bitmap rows)
-constexpr int kPosWords = (kMaxBubbles + 32) / 32;  // u32 words of a position bit mask in LDS
-constexpr int kWinWords = 32;       // u64 words of k_readset's per-alignment node window
+constexpr int kMaxBubbles = 1023;   // positions are 10-bit fields of sort keys
+constexpr int kMaxNodes = 2048;     // per-alignment node bitset: 32 x u64 in LDS
+constexpr int kMaxNames = 4096;     // distinct read names per chain (k_readset LDS)
+constexpr int kMaxReads = 2048;     // reads in the final readset (k_phase LDS)
 constexpr int kMaxAlleles = 16;     // alleles per bubble (4 bit planes)
 constexpr int kMaxPloidy = 4;       // tuples = (2p)^p <= 4096
 constexpr int kBlock = 256;         // threads per workgroup (4 wavefronts)
-constexpr size_t kReadsetFitBytes = 144 * 1024;  // LDS budget of k_readset_lds per chain (at least one workgroup per CU of 160 KB)
+constexpr size_t kReadsetFitBytes = 64 * 1024;  // LDS budget of k_readset_lds per chain (two or more workgroups per CU)
 
 constexpr int32_t W_PERM = 0x7fffffff;
 constexpr int32_t W_FORB = -0x7fffffff;  // -INT_MAX: its negation is W_PERM
@@ -139,18 +130,16 @@ struct PhaseLds {
   int stage_row;   // 1: room for the staged weight row (4 B per read) -- set when it does not cost a workgroup per CU
   int items_lds;   // 1: the first 2*nmax candidate edges of an iteration are listed in LDS (8 B per read), 0: all in HBM
                    //    -- dropped when that buys a workgroup per CU
-  int nwv;         // wavefronts per workgroup: 4 (throughput form; 0 means 4) or 8 / 16 (latency forms, k_phase.hip)
 };
-struct ReadsetLds2 {  // k_readset_lds: the sizes ONE chain's LDS layout follows from
-  int maxBitWords;   // ceil(N/64) * R: u64 words of all alignment bitsets
-  int maxMaskWords;  // ceil(N/64) * alleles: u64 words of one set of allele-path masks
+struct ReadsetLds2 {  // k_readset_lds
+  int maxBitWords;   // max over its chains of ceil(N/64) * R: u64 words of all alignment bitsets
+  int maxMaskWords;  // max of ceil(N/64) * alleles: u64 words of one set of allele-path masks
   int maxR, maxG, maxB, maxSA;
 };
 size_t readset_lds_bytes(const ReadsetLds& l);
 size_t readset_lds2_bytes(const ReadsetLds2& l);
 void launch_readset(const DeviceBatch& db, const int* list, int count, const ReadsetLds& l, hipStream_t stream);
-// lds_bytes: the largest readset_lds2_bytes need among the listed chains; maxG: their largest name count
-void launch_readset_lds(const DeviceBatch& db, const int* list, int count, size_t lds_bytes, int maxG, hipStream_t stream);
+void launch_readset_lds(const DeviceBatch& db, const int* list, int count, const ReadsetLds2& l, hipStream_t stream);
 size_t phase_lds_bytes(const PhaseLds& l);
 // ctl: three device ints of the class -- cursor of the queue, cursor of the deferred list, length of the
 // deferred list -- zeroed by the caller before every call; deferred: [C] device ints

@@ -42,6 +42,18 @@ def main():
     t7 = time.perf_counter()
     bub = r2.phased_bubbles(b.arrays()["bubble_off"])
     out.update({"phase_batch_s": round(t7 - t6, 3), "phased_bubbles": int(bub), "end_to_end_bubbles_per_s": round(bub / (t7 - t6))})
+    # the in-process multi-device entry: host time before the first upload with eight device threads (the
+    # serial part -- cost model and partition -- plus the longest per-shard view / pack, which the device
+    # threads do concurrently), and one call over {0,0,...}: eight shards side by side on this one GPU
+    _, blocks, serial_ms, shard_ms = capi.multi_plan(b, 8, prm, check=False)
+    out.update({"multi8_partition": "blocks (zero-copy views)" if blocks else "LPT (packed copies)",
+                "multi8_host_serial_ms": round(serial_ms, 2), "multi8_host_shard_ms_max": round(shard_ms, 2),
+                "multi8_host_before_first_upload_ms": round(serial_ms + shard_ms, 2)})
+    t8 = time.perf_counter()
+    r3 = capi.phase_batch_multi(b, [0] * 8, prm)
+    t9 = time.perf_counter()
+    assert (r3.hap_allele == r2.hap_allele).all() and (r3.status == r2.status).all()
+    out.update({"multi8_same_gpu_s": round(t9 - t8, 3), "multi8_equals_single": True})
     print(json.dumps(out))
 
 
