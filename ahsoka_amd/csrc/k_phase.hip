@@ -62,6 +62,37 @@
 #define AHK_F(slot) do {} while (0)
 #endif
 
+// Diagnostic build only (-DAHK_LINES): workgroup 0 counts, per load/store site of the S5 loop, the wave
+// instructions issued and the distinct 128-B lines they touch (what the L1 asks the L2 for if nothing hits);
+// printed per chain (tools/lines.sh).  The product build compiles none of this.
+#ifdef AHK_LINES
+__shared__ unsigned long long g_lines[32], g_reqs[32], g_lanes[32];
+__device__ __noinline__ void ahk_count_lines(int slot, const void* p) {
+  if (blockIdx.x != 0) return;
+  const unsigned long long a = (unsigned long long)p >> 7;
+  const unsigned long long ex = __ballot(true);
+  unsigned long long rem = ex;
+  int cnt = 0;
+  while (rem != 0ull) {
+    const int l = __builtin_ctzll(rem);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)a, l);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(a >> 32), l);
+    const unsigned long long al = ((unsigned long long)hi << 32) | lo;
+    rem &= ~__ballot(a == al);
+    cnt++;
+  }
+  const int me = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  if (me == __builtin_ctzll(ex)) {
+    atomicAdd(&g_lines[slot], (unsigned long long)cnt);
+    atomicAdd(&g_reqs[slot], 1ull);
+    atomicAdd(&g_lanes[slot], (unsigned long long)__popcll(ex));
+  }
+}
+#define AHK_L(slot, ptr) ahk_count_lines(slot, (const void*)(ptr))
+#else
+#define AHK_L(slot, ptr) do {} while (0)
+#endif
+
 // tuning switches (tools/variants.sh builds and benches combinations on one box)
 #ifndef AHK_P3B_SINGLE
 #define AHK_P3B_SINGLE 1
@@ -332,6 +363,7 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
                                              const IcT* __restrict__ IC, unsigned long long* keys /* F0 P0 F1 P1 */) {
   const unsigned long long bm0 = lane < nw ? LV_AT((unsigned)(r0 * nw + lane)) : 0ull;
   const unsigned long long bm1 = (r1 >= 0 && lane < nw) ? LV_AT((unsigned)(r1 * nw + lane)) : 0ull;
+  if (lane < nw) { AHK_L(5, &LV_AT((unsigned)(r0 * nw + lane))); if (r1 >= 0) AHK_L(5, &LV_AT((unsigned)(r1 * nw + lane))); }
   unsigned long long todo0 = __ballot(bm0 != 0ull), todo1 = __ballot(bm1 != 0ull);
   unsigned long long kF0 = 0, kP0 = 0, kF1 = 0, kP1 = 0;
   while ((todo0 | todo1) != 0ull) {
@@ -359,6 +391,7 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
       if (l >= 0 && ((w >> lane) & 1ull)) {
         col[c] = (l << 6) + lane;
         v[c] = IC_AT(ic_index(second[c] ? r1 : r0, col[c], n));
+        AHK_L(6, &IC_AT(ic_index(second[c] ? r1 : r0, col[c], n)));
       }
     }
 #pragma unroll
@@ -517,7 +550,7 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
 // nothing and read as 0,0: all four terms vanish.
 template <int Nv>
 __device__ __forceinline__ void tri_seg(const int* __restrict__ Wm, int n, int x, int b, const unsigned short* L, int cnt,
-                                        long long& df, long long& dp) {
+                                        long long& df, long long& dp, int lslot = 12) {
   int w0 = 0;
 #if AHK_P3B_SINGLE
   // a single member (one read opposite a clique): the most common list of all
@@ -526,6 +559,8 @@ __device__ __forceinline__ void tri_seg(const int* __restrict__ Wm, int n, int x
     // (W is symmetric: W[x][w] is read as W[w][x] -- row w is the row every edge of this
     // iteration reads its third edge from, row x would be one more HBM line per row x)
     const int ov = WM_AT((unsigned)(w * n + x)), wb = WM_AT((unsigned)(w * n + b));
+    AHK_L(lslot, &WM_AT((unsigned)(w * n + x)));
+    AHK_L(lslot, &WM_AT((unsigned)(w * n + b)));
     df += icf_term(Nv, wb) - icf_term(ov, wb);
     dp += icp_term(Nv, wb) - icp_term(ov, wb);
     return;
@@ -541,6 +576,8 @@ __device__ __forceinline__ void tri_seg(const int* __restrict__ Wm, int n, int x
     for (int c = 0; c < 4; c++) {
       ovv[c] = WM_AT((unsigned)(x * n + wq[c]));
       wbv[c] = WM_AT((unsigned)(wq[c] * n + b));
+      AHK_L(lslot, &WM_AT((unsigned)(x * n + wq[c])));
+      AHK_L(lslot + 1, &WM_AT((unsigned)(wq[c] * n + b)));
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -557,6 +594,7 @@ __device__ __forceinline__ void tri_seg(const int* __restrict__ Wm, int n, int x
       const int w = ok ? (int)L[w0 + c] : 0;
       ovv[c] = ok ? WM_AT((unsigned)(x * n + w)) : 0;
       wbv[c] = ok ? WM_AT((unsigned)(w * n + b)) : 0;
+      if (ok) { AHK_L(lslot, &WM_AT((unsigned)(x * n + w))); AHK_L(lslot + 1, &WM_AT((unsigned)(w * n + b))); }
     }
 #pragma unroll
     for (int c = 0; c < kP3bChunk; c++) {
@@ -572,7 +610,7 @@ __device__ __forceinline__ void tri_seg(const int* __restrict__ Wm, int n, int x
 // length is what counts; it has few live values, sixteen loads in flight fit the registers.
 template <int Nv>
 __device__ __forceinline__ void tri_seg_wide(const int* __restrict__ Wm, int n, int x, int b, const unsigned short* L, int cnt,
-                                             long long& df, long long& dp) {
+                                             long long& df, long long& dp, int lslot = 14) {
   int w0 = 0;
   for (; w0 + 8 <= cnt; w0 += 8) {
     const uint4 pk = *reinterpret_cast<const uint4*>(L + w0);
@@ -583,6 +621,8 @@ __device__ __forceinline__ void tri_seg_wide(const int* __restrict__ Wm, int n, 
     for (int c = 0; c < 8; c++) {
       ovv[c] = WM_AT((unsigned)(x * n + wq[c]));
       wbv[c] = WM_AT((unsigned)(wq[c] * n + b));
+      AHK_L(lslot, &WM_AT((unsigned)(x * n + wq[c])));
+      AHK_L(lslot + 1, &WM_AT((unsigned)(wq[c] * n + b)));
     }
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -590,7 +630,7 @@ __device__ __forceinline__ void tri_seg_wide(const int* __restrict__ Wm, int n, 
       dp += icp_term(Nv, wbv[c]) - icp_term(ovv[c], wbv[c]);
     }
   }
-  if (w0 < cnt) tri_seg<Nv>(Wm, n, x, b, L + w0, cnt - w0, df, dp);
+  if (w0 < cnt) tri_seg<Nv>(Wm, n, x, b, L + w0, cnt - w0, df, dp, lslot);
 }
 
 #ifndef AHK_WAVES_PER_SIMD
@@ -953,6 +993,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
 
     // ================= S5 main loop ========================================
     long long iters = 0;
+#ifdef AHK_LINES
+    if (tid < 32) { g_lines[tid] = 0ull; g_reqs[tid] = 0ull; g_lanes[tid] = 0ull; }
+    __syncthreads();
+#endif
 #ifdef AHK_FTRACE
     if (tid < 64) s_ft[tid >> 4][tid & 15] = 0ull;
     __syncthreads();
@@ -1053,6 +1097,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         if (lane < nw) {
           lvn = LV_AT((unsigned)(x * nw + lane));
           nzo = NZ_AT((unsigned)(w * nw + lane));
+          AHK_L(0, &LV_AT((unsigned)(x * nw + lane)));
+          AHK_L(1, &NZ_AT((unsigned)(w * nw + lane)));
         }
         const int ov = WM_AT((unsigned)(eu * n + ev));  // wave-uniform
         if (lane == (w >> 6)) {
@@ -1092,7 +1138,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
                 const int b = (lw[c] << 6) + lane;
                 on[c] = true;
                 icv[c] = IC_AT(ic_index(x, b, n));
-                if ((cd >> lane) & 1ull) wb[c] = WM_AT((unsigned)(w * n + b));
+                AHK_L(2, &IC_AT(ic_index(x, b, n)));
+                if ((cd >> lane) & 1ull) { wb[c] = WM_AT((unsigned)(w * n + b)); AHK_L(3, &WM_AT((unsigned)(w * n + b))); }
               }
             }
           }
@@ -1108,6 +1155,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
               ic.p += dp;
               IC_AT(ic_index(x, b, n)) = ic;
               IC_AT(ic_index(b, x, n)) = ic;
+              AHK_L(4, &IC_AT(ic_index(b, x, n)));
             }
             const unsigned long long r1 = mkkey(ic.f, x, b), r2 = mkkey(ic.p, x, b);
             if (df != 0 || dp != 0) {
@@ -1119,6 +1167,24 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           }
         }
         AHK_F(5);
+#if defined(AHK_PROBE_VALU) || defined(AHK_PROBE_SALU)
+        // sensitivity probe (diagnostic builds only): N extra dependent vector / scalar instructions per wave
+        // and single-read separation -- what does an instruction cost in this loop?  (tools/probe.sh)
+        {
+#ifdef AHK_PROBE_VALU
+          unsigned int pv = (unsigned int)lane;
+#pragma unroll
+          for (int q = 0; q < AHK_PROBE_VALU; q++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pv));
+          if (pv == 0xffffffffu) kF = 0ull;  // (never: keeps the chain alive)
+#endif
+#ifdef AHK_PROBE_SALU
+          unsigned int ps = (unsigned int)wv;
+#pragma unroll
+          for (int q = 0; q < AHK_PROBE_SALU; q++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ps) : : "scc");
+          if (ps == 0xffffffffu) kF = 0ull;
+#endif
+        }
+#endif
         kF = wave_max_u64(kF);
         kP = wave_max_u64(kP);
         if (lane == 0) { s_rk[wv] = kF; s_rk[NWV + wv] = kP; }
@@ -1162,7 +1228,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
       const int rs = !lds.stage_row ? -1
                                     : __builtin_amdgcn_readfirstlane(!((multiw[eu >> 5] >> (eu & 31)) & 1u) ? eu : (!((multiw[ev >> 5] >> (ev & 31)) & 1u) ? ev : -1));
       if (rs >= 0)
-        for (int z = tid; z < n; z += kThreads) wrow[z] = WM_AT((unsigned)(rs * n + z));
+        for (int z = tid; z < n; z += kThreads) { wrow[z] = WM_AT((unsigned)(rs * n + z)); AHK_L(8, &WM_AT((unsigned)(rs * n + z))); }
 
       // ---- P2: roles, member lists and per-word role masks --------------------
       // (s_cnt was zeroed before the last barrier).  rmask[R][k] has bit c set iff
@@ -1177,6 +1243,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           else if (cz == cv) r = ROLE_B;
           else if (merge) {
             const bool fa = WM_AT((unsigned)(eu * n + z)) == W_FORB, fb = WM_AT((unsigned)(ev * n + z)) == W_FORB;
+            AHK_L(7, &WM_AT((unsigned)(eu * n + z)));
+            AHK_L(7, &WM_AT((unsigned)(ev * n + z)));
             if (fa && !fb) r = ROLE_FA;
             if (fb && !fa) r = ROLE_FB;
           }
@@ -1241,7 +1309,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
             unsigned long long t[8];
 #pragma unroll
             for (int c = 0; c < 8; c++)
+            {
               t[c] = (w0 + c < nr) ? NZ_AT((unsigned)(__builtin_amdgcn_readfirstlane((int)Lr[w0 + c < nr ? w0 + c : 0]) * nw + lane)) : 0ull;
+              if (w0 + c < nr) AHK_L(9, &NZ_AT((unsigned)(__builtin_amdgcn_readfirstlane((int)Lr[w0 + c < nr ? w0 + c : 0]) * nw + lane)));
+            }
 #pragma unroll
             for (int c = 0; c < 8; c++) acc |= t[c];
           }
@@ -1305,6 +1376,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           if (x_nx >= 0 && wordok) {
             lv_nx = LV_AT((unsigned)(x_nx * nw + kw));
             nz_nx = NZ_AT((unsigned)(x_nx * nw + kw));
+            AHK_L(10, &LV_AT((unsigned)(x_nx * nw + kw)));
+            AHK_L(11, &NZ_AT((unsigned)(x_nx * nw + kw)));
           }
           // the role of x follows from which list it came from
           const int rx = xi < nA ? ROLE_A : xi < nA + nB ? ROLE_B : xi < nA + nB + nFa ? ROLE_FA : ROLE_FB;
@@ -1388,7 +1461,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
                 mbits &= mbits - 1ull;
                 const unsigned int it = ((unsigned)rx << 28) | ((unsigned)role[b] << 24) | ((unsigned)x << 12) | (unsigned)b;
                 if (idx < cap) items_lds[idx] = it;
-                else items_glb[idx - cap] = it;
+                else { items_glb[idx - cap] = it; AHK_L(24, &items_glb[idx - cap]); }
                 idx++;
               }
             }
@@ -1405,7 +1478,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
                 const int id2 = basel + mask_rank(w);
                 const unsigned int it = ((unsigned)rxl << 28) | ((unsigned)role[b] << 24) | ((unsigned)xl << 12) | (unsigned)b;
                 if (id2 < cap) items_lds[id2] = it;
-                else items_glb[id2 - cap] = it;
+                else { items_glb[id2 - cap] = it; AHK_L(24, &items_glb[id2 - cap]); }
               }
             }
           }
@@ -1489,6 +1562,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
                 ws4[c] = w;
                 ov4[c] = w >= 0 ? WM_AT((unsigned)(x * n + w)) : 0;
                 wb4[c] = w >= 0 ? WM_AT((unsigned)(w * n + b)) : 0;
+                if (w >= 0) { AHK_L(18, &WM_AT((unsigned)(x * n + w))); AHK_L(18, &WM_AT((unsigned)(w * n + b))); }
               }
 #pragma unroll
               for (int c = 0; c < kP3bChunk; c++) {
@@ -1521,6 +1595,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
                 const int Nv = new_w(rb, rw, merge);
                 const int ov = WM_AT((unsigned)(w * n + b));
                 const int xw = WM_AT((unsigned)(x * n + w));
+                AHK_L(18, &WM_AT((unsigned)(w * n + b)));
+                AHK_L(18, &WM_AT((unsigned)(x * n + w)));
                 df += icf_term(Nv, xw) - icf_term(ov, xw);
                 dp += icp_term(Nv, xw) - icp_term(ov, xw);
               }
@@ -1533,6 +1609,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
 #if AHK_IC_LATE
           IcT ic = IC_AT(ici);
 #endif
+          AHK_L(16, &IC_AT(ici));
+          AHK_L(17, &IC_AT(ic_index(b, x, n)));
           ic.f += df;
           ic.p += dp;
           IC_AT(ici) = ic;
@@ -1578,6 +1656,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
             staged_delta(it, df, dp);
             const unsigned ici = ic_index(x, b, n);
             IcT ic = IC_AT(ici);
+            AHK_L(19, &IC_AT(ici));
+            AHK_L(20, &IC_AT(ic_index(b, x, n)));
             ic.f += df;
             ic.p += dp;
             IC_AT(ici) = ic;
@@ -1775,6 +1855,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
                 const int b = (int)(it & 0xfffu);
                 const unsigned ici = ic_index(x, b, n);
                 IcT ic = IC_AT(ici);
+                AHK_L(21, &IC_AT(ici));
+                AHK_L(22, &IC_AT(ic_index(b, x, n)));
                 ic.f += df;
                 ic.p += dp;
                 IC_AT(ici) = ic;
@@ -1901,6 +1983,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
             }
             WM_AT((unsigned)(x * n + y)) = N;
             WM_AT((unsigned)(y * n + x)) = N;
+            AHK_L(23, &WM_AT((unsigned)(x * n + y)));
+            AHK_L(23, &WM_AT((unsigned)(y * n + x)));
           }
         }
         if (merge) {
@@ -1972,6 +2056,19 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           if (h2[b * 4 + q]) printf("ncmax<=%d ncmin_bucket=%d: iters=%lld Mcyc=%lld avgM=%lld\n", 2 << b, q, h2[b * 4 + q], h2c[b * 4 + q] / 1000000, h2m[b * 4 + q] / h2[b * 4 + q]);
       for (int b = 0; b < 8; b++) printf("M<=%d: iters=%lld cyc/iter=%lld | T<=%d: iters=%lld cyc/iter=%lld\n", 32 << b, hM[b], hM[b] ? hMc[b] / hM[b] : 0, 2 << b, hT[b], hT[b] ? hTc[b] / hT[b] : 0);
     }
+#endif
+#ifdef AHK_LINES
+    if (tid == 0 && blockIdx.x == 0) {
+      unsigned long long tot = 0ull;
+      for (int q = 0; q < 32; q++) tot += g_lines[q];
+      printf("lines chain %d n=%d iters=%lld total_lines=%llu\n", c, n, iters, tot);
+      for (int q = 0; q < 32; q++) {  // (one value per call: the device printf garbles longer argument lists)
+        printf("lines site %d insts %llu\n", q, g_reqs[q]);
+        printf("lines site %d lanes %llu\n", q, g_lanes[q]);
+        printf("lines site %d lines %llu\n", q, g_lines[q]);
+      }
+    }
+    __syncthreads();
 #endif
 #ifdef AHK_DIAG
     if (lds.stop_after == 3) continue;
