@@ -349,6 +349,37 @@ __device__ __forceinline__ int new_w(int r1, int r2, bool merge) {
 // the second, scattered store.  (A single copy at [min][max] made half of all
 // reads column accesses: one HBM line per 16 useful bytes.)
 __device__ __forceinline__ unsigned ic_index(int r, int c, int n) { return (unsigned)(r * n + c); }
+// LIVE-WORD SUMMARY (LDS, 16 bits per read): bit i of lwm[r] is set while the bitmap words [i << glog, (i + 1) << glog) of
+// row r may hold a live edge (glog = 0 for rows of at most 16 words -- the bit then says exactly "word i is not empty" --,
+// 1 up to 32 words, 2 up to 64; a set bit over an empty word only costs a load that is masked out afterwards, a clear
+// bit over a live edge would be a wrong result: bits are cleared only by the lane that has just written a zero word,
+// and only for glog == 0).  With it a pass that scans a row's induced costs knows which 64-column words to ask for
+// WITHOUT first waiting for the row's bitmap: the bitmap words and the induced costs travel in the same round trip.
+#ifndef AHK_LWM
+#define AHK_LWM 1  // 0: bitmap first, then the induced costs of the live words (two dependent round trips)
+#endif
+__device__ __forceinline__ unsigned long long lwm_words(unsigned int m, int glog, int nw) {
+  unsigned long long t = m;
+  if (glog == 1) {
+    t = (t | (t << 8)) & 0x00ff00ffull;
+    t = (t | (t << 4)) & 0x0f0f0f0full;
+    t = (t | (t << 2)) & 0x33333333ull;
+    t = (t | (t << 1)) & 0x55555555ull;
+    t |= t << 1;
+  } else if (glog == 2) {
+    t = (t | (t << 24)) & 0x000000ff000000ffull;
+    t = (t | (t << 12)) & 0x000f000f000f000full;
+    t = (t | (t << 6)) & 0x0303030303030303ull;
+    t = (t | (t << 3)) & 0x1111111111111111ull;
+    t *= 15ull;
+  }
+  return nw >= 64 ? t : (t & ((1ull << nw) - 1ull));
+}
+// (two rows share a 32-bit word of the summary: the atomic leaves the other row's half alone)
+__device__ __forceinline__ void lwm_clear(unsigned short* lwm, int r, int bit) {
+  atomicAnd((unsigned int*)lwm + (r >> 1), ~((1u << bit) << ((r & 1) << 4)));
+}
+
 // Exact maxima of rows r0 and r1 (r1 < 0: none) over their live edges.  Lane = bit
 // of a 64-column bitmap word; the non-empty words of both rows form one work list
 // that is consumed four words at a time: the four induced-cost loads of a batch are
@@ -360,45 +391,56 @@ __device__ __forceinline__ unsigned ic_index(int r, int c, int n) { return (unsi
 constexpr int kRescanBatch = AHK_RESCAN_BATCH;  // bitmap words of a rescan whose induced costs are requested together
 template <class IcT>
 __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int lane, const unsigned long long* __restrict__ LV,
-                                             const IcT* __restrict__ IC, unsigned long long* keys /* F0 P0 F1 P1 */) {
+                                             const IcT* __restrict__ IC, const unsigned short* lwm, int glog, unsigned long long* keys /* F0 P0 F1 P1 */) {
   const unsigned long long bm0 = lane < nw ? LV_AT((unsigned)(r0 * nw + lane)) : 0ull;
   const unsigned long long bm1 = (r1 >= 0 && lane < nw) ? LV_AT((unsigned)(r1 * nw + lane)) : 0ull;
   if (lane < nw) { AHK_L(5, &LV_AT((unsigned)(r0 * nw + lane))); if (r1 >= 0) AHK_L(5, &LV_AT((unsigned)(r1 * nw + lane))); }
+#if AHK_LWM
+  // the words to scan come from the LDS summary: their induced costs are requested together with the bitmap rows
+  unsigned long long todo0 = lwm_words((unsigned)__builtin_amdgcn_readfirstlane((int)lwm[r0]), glog, nw);
+  unsigned long long todo1 = r1 >= 0 ? lwm_words((unsigned)__builtin_amdgcn_readfirstlane((int)lwm[r1]), glog, nw) : 0ull;
+#else
   unsigned long long todo0 = __ballot(bm0 != 0ull), todo1 = __ballot(bm1 != 0ull);
+#endif
   unsigned long long kF0 = 0, kP0 = 0, kF1 = 0, kP1 = 0;
   while ((todo0 | todo1) != 0ull) {
     IcT v[kRescanBatch];
-    int col[kRescanBatch];
+    int wl[kRescanBatch];
     bool second[kRescanBatch];
 #pragma unroll
     for (int c = 0; c < kRescanBatch; c++) {
-      col[c] = -1;
+      wl[c] = -1;
       second[c] = false;
       v[c].f = 0;  // (defined on every path: an undefined value becomes a register that lives across the caller's loop)
       v[c].p = 0;
-      int l = -1;
-      unsigned long long w = 0ull;
       if (todo0 != 0ull) {
-        l = __builtin_ctzll(todo0);
+        wl[c] = __builtin_ctzll(todo0);
         todo0 &= todo0 - 1ull;
-        w = readlane_u64(bm0, l);
       } else if (todo1 != 0ull) {
-        l = __builtin_ctzll(todo1);
+        wl[c] = __builtin_ctzll(todo1);
         todo1 &= todo1 - 1ull;
-        w = readlane_u64(bm1, l);
         second[c] = true;
       }
-      if (l >= 0 && ((w >> lane) & 1ull)) {
-        col[c] = (l << 6) + lane;
-        v[c] = IC_AT(ic_index(second[c] ? r1 : r0, col[c], n));
-        AHK_L(6, &IC_AT(ic_index(second[c] ? r1 : r0, col[c], n)));
+#if AHK_LWM
+      if (wl[c] >= 0) {  // uniform: every lane of the word asks (the last word's lanes beyond the row stay inside it)
+        const int col = (wl[c] << 6) + lane;
+        v[c] = IC_AT(ic_index(second[c] ? r1 : r0, col < n ? col : n - 1, n));
+        AHK_L(6, &IC_AT(ic_index(second[c] ? r1 : r0, col < n ? col : n - 1, n)));
       }
+#else
+      if (wl[c] >= 0 && ((readlane_u64(second[c] ? bm1 : bm0, wl[c]) >> lane) & 1ull)) {
+        v[c] = IC_AT(ic_index(second[c] ? r1 : r0, (wl[c] << 6) + lane, n));
+        AHK_L(6, &IC_AT(ic_index(second[c] ? r1 : r0, (wl[c] << 6) + lane, n)));
+      }
+#endif
     }
 #pragma unroll
     for (int c = 0; c < kRescanBatch; c++) {
-      if (col[c] < 0) continue;
-      const int rr = second[c] ? r1 : r0;
-      const unsigned long long k1 = mkkey(v[c].f, rr, col[c]), k2 = mkkey(v[c].p, rr, col[c]);
+      if (wl[c] < 0) continue;
+      const unsigned long long w = readlane_u64(second[c] ? bm1 : bm0, wl[c]);
+      if (((w >> lane) & 1ull) == 0ull) continue;
+      const int rr = second[c] ? r1 : r0, col = (wl[c] << 6) + lane;
+      const unsigned long long k1 = mkkey(v[c].f, rr, col), k2 = mkkey(v[c].p, rr, col);
       if (second[c]) {
         kF1 = k1 > kF1 ? k1 : kF1;
         kP1 = k2 > kP1 ? k2 : kP1;
@@ -422,13 +464,13 @@ __device__ __forceinline__ void rescan_rows2(int r0, int r1, int n, int nw, int 
 template <class IcT, int NWV>
 __device__ __forceinline__ void rescan_list(const unsigned short* dlist, int nd, int wv, int lane, int n, int nw,
                                             const unsigned long long* __restrict__ LV, const IcT* __restrict__ IC,
-                                            unsigned long long* bestF, unsigned long long* bestP) {
+                                            const unsigned short* lwm, int glog, unsigned long long* bestF, unsigned long long* bestP) {
   for (int di = 2 * wv; di < nd; di += 2 * NWV) {
     // (the rows are wave-uniform: as scalars, their address arithmetic runs on the scalar unit)
     const int r0 = __builtin_amdgcn_readfirstlane((int)dlist[di]);
     const int r1 = di + 1 < nd ? __builtin_amdgcn_readfirstlane((int)dlist[di + 1]) : -1;
     unsigned long long keys[4];
-    rescan_rows2(r0, r1, n, nw, lane, LV, IC, keys);
+    rescan_rows2(r0, r1, n, nw, lane, LV, IC, lwm, glog, keys);
     if (lane == 0) {
       bestF[r0] = keys[0];
       bestP[r0] = keys[1];
@@ -697,7 +739,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
   // per-wave scratch of S4a (key buffer, u32) and S5 init (neighbour list, u16): the four-wave form
   // re-uses bestF/bestP and the role lists, which hold exactly four such buffers; the wide forms
   // have a region of their own (one workgroup or two per CU: the LDS is there)
-  unsigned int* wscr = NWV > 4 ? (unsigned int*)(((size_t)(wrow + (lds.stage_row ? nmax : 0)) + 7) & ~(size_t)7) : nullptr;  // [NWV][nmax]
+  unsigned short* lwm = (unsigned short*)(wrow + (lds.stage_row ? nmax : 0));  // [nmax] live-word summary of every row (see lwm_words)
+  unsigned int* wscr = NWV > 4 ? (unsigned int*)(((size_t)(lwm + nmax) + 7) & ~(size_t)7) : nullptr;  // [NWV][nmax]
   __shared__ int s_chain, s_cnt[4], s_nd, s_items, s_nh, s_nslow;
   __shared__ unsigned short s_pref[4][64];
 #ifdef AHK_TIMING
@@ -881,6 +924,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
     // words per row rounded up to a power of two (>= 8): lane layout of the row passes
     const int nwp_log = nw <= 8 ? 3 : nw <= 16 ? 4 : nw <= 32 ? 5 : 6;
     const int nwp = 1 << nwp_log;
+    const int glog = nw <= 16 ? 0 : nw <= 32 ? 1 : 2;  // bitmap words per bit of the live-word summary, as a shift
     const int RP = 64 >> nwp_log;  // rows a wave handles at once
     // Each unordered pair {a,b} is computed once, by the wave of its lower end a (lanes = the
     // neighbours b > a), and stored for both orientations; the row maxima are folded in with LDS
@@ -903,6 +947,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
       for (int a0 = wv * kInitRows; a0 < n; a0 += NWV * kInitRows) {
         const int R = n - a0 < kInitRows ? n - a0 : kInitRows;
         int deg = 0, dhi = 0;
+        unsigned int lw0[kInitRows];  // the rows' live-word summaries
+#pragma unroll
+        for (int r = 0; r < kInitRows; r++) lw0[r] = 0u;
         for (int w0 = 0; w0 < n; w0 += 64) {
           const int w = w0 + lane;
           bool nzu = false;
@@ -914,6 +961,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
               LV_AT((unsigned)((a0 + r) * nw + (w0 >> 6))) = mk;
               NZ_AT((unsigned)((a0 + r) * nw + (w0 >> 6))) = mk;
             }
+            if (mk != 0ull) lw0[r] |= 1u << ((w0 >> 6) >> glog);
             nzu = nzu || nz;
           }
           const unsigned long long mu = __ballot(nzu);
@@ -922,6 +970,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           deg += __popcll(mu);
           dhi += __popcll(mh);
         }
+#pragma unroll
+        for (int r = 0; r < kInitRows; r++)
+          if (r < R && lane == 0) lwm[a0 + r] = (unsigned short)lw0[r];
         // lanes = the union's members b > a0 (the tail of the ascending list): a pair (a_r, b) of the
         // group is this wave's iff b > a_r and W[a_r][b] != 0.  The rows' own weights W[a_r][w] are
         // wave-uniform: 64 of them per row come with ONE load (lane = list index) and are handed out
@@ -1063,7 +1114,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         }
         __syncthreads();
         {
-          rescan_list<IcT, NWV>(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
+          rescan_list<IcT, NWV>(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, lwm, glog, bestF, bestP);
         }
         __syncthreads();
 #ifdef AHK_TIMING
@@ -1101,11 +1152,20 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           AHK_L(1, &NZ_AT((unsigned)(w * nw + lane)));
         }
         const int ov = WM_AT((unsigned)(eu * n + ev));  // wave-uniform
+#if AHK_LWM
+        // ONE round trip: the words of row x that may hold a live edge are known from the LDS summary, so the
+        // induced costs of those words and the third-edge weights W[w][.] of the same columns are requested
+        // together with the two bitmap rows (every lane of a word asks: a row's live edges are spread over all
+        // four lines of a word's induced costs anyway) and masked with the bitmaps once everything is here.
+        unsigned long long todo = lwm_words((unsigned)__builtin_amdgcn_readfirstlane((int)lwm[x]), glog, nw);
+        bool first = true;
+#else
         if (lane == (w >> 6)) {
           lvn &= ~(1ull << (w & 63));
           if (sub == 0) LV_AT((unsigned)(x * nw + lane)) = lvn;
         }
         unsigned long long todo = __ballot(lvn != 0ull);
+#endif
         unsigned long long kF = 0ull, kP = 0ull;
         AHK_F(4);
         // this wave takes the live words whose rank is sub modulo NSUB (four waves: even / odd rank), kFastBatch per trip
@@ -1125,6 +1185,42 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           IcT icv[kFastBatch];
           int wb[kFastBatch];
           bool on[kFastBatch];
+#if AHK_LWM
+#pragma unroll
+          for (int c = 0; c < kFastBatch; c++) {
+            icv[c].f = 0;  // (defined on every path, see rescan_rows2)
+            icv[c].p = 0;
+            wb[c] = 0;
+            if (lw[c] >= 0) {  // uniform
+              const int b = (lw[c] << 6) + lane;
+              const int bc = b < n ? b : n - 1;  // (lanes beyond the row stay inside it; their bits are clear)
+              icv[c] = IC_AT(ic_index(x, bc, n));
+              wb[c] = WM_AT((unsigned)(w * n + bc));
+              AHK_L(2, &IC_AT(ic_index(x, bc, n)));
+              AHK_L(3, &WM_AT((unsigned)(w * n + bc)));
+            }
+          }
+          if (first) {  // uniform: the edge (x, w) itself dies
+            first = false;
+            if (lane == (w >> 6)) {
+              lvn &= ~(1ull << (w & 63));
+              if (sub == 0) {
+                LV_AT((unsigned)(x * nw + lane)) = lvn;
+                if (glog == 0 && lvn == 0ull) lwm_clear(lwm, x, lane);
+              }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < kFastBatch; c++) {
+            on[c] = false;
+            if (lw[c] >= 0) {
+              const unsigned long long wd = readlane_u64(lvn, lw[c]);
+              const unsigned long long cd = wd & readlane_u64(nzo, lw[c]);
+              on[c] = ((wd >> lane) & 1ull) != 0ull;
+              if (((cd >> lane) & 1ull) == 0ull) wb[c] = 0;
+            }
+          }
+#else
 #pragma unroll
           for (int c = 0; c < kFastBatch; c++) {
             on[c] = false;
@@ -1143,6 +1239,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
               }
             }
           }
+#endif
 #pragma unroll
           for (int c = 0; c < kFastBatch; c++) {
             if (!on[c]) continue;
@@ -1166,6 +1263,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
             kP = r2 > kP ? r2 : kP;
           }
         }
+#if AHK_LWM
+        if (first && lane == (w >> 6)) {  // (a row whose summary was empty: only the dying edge's word is rewritten)
+          lvn &= ~(1ull << (w & 63));
+          if (sub == 0) LV_AT((unsigned)(x * nw + lane)) = lvn;
+        }
+#endif
         AHK_F(5);
 #if defined(AHK_PROBE_VALU) || defined(AHK_PROBE_SALU)
         // sensitivity probe (diagnostic builds only): N extra dependent vector / scalar instructions per wave
@@ -1398,7 +1501,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           if (x >= 0 && wordok) {
             const unsigned long long lvn = lvw & ~D;
             const unsigned long long nzn = nzw | D;
-            if (lvn != lvw) LV_AT((unsigned)(x * nw + kw)) = lvn;
+            if (lvn != lvw) {
+              LV_AT((unsigned)(x * nw + kw)) = lvn;
+              if (glog == 0 && lvn == 0ull) lwm_clear(lwm, x, kw);
+            }
             if (nzn != nzw) NZ_AT((unsigned)(x * nw + kw)) = nzn;
             const int xw = x >> 6;
             const unsigned long long low = kw < xw ? ~0ull : (kw == xw ? ((1ull << (x & 63)) - 1ull) : 0ull);
@@ -2002,7 +2108,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         if (tid == 0) { s_items = 0; s_nh = 0; s_nslow = 0; }
         AHK_T(6);  // (diagnostic build: weight rewrites vs rescans)
         // rows whose maximum died: exact rescan now (they would tie the next argmax anyway)
-        rescan_list<IcT, NWV>(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, bestF, bestP);
+        rescan_list<IcT, NWV>(dlist, __builtin_amdgcn_readfirstlane(s_nd), wv, lane, n, nw, LV, IC, lwm, glog, bestF, bestP);
         AHK_T(7);
       }
       __syncthreads();
@@ -2486,6 +2592,7 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   b += (size_t)2 * 4 * rw * 8;             // rmask, rolenz (and the per-wave pending lists that re-use them)
   b += (size_t)l.nmax;                     // role
   if (l.stage_row) b += (size_t)l.nmax * 4;  // wrow
+  b += (size_t)l.nmax * 2;                 // lwm
   if (nwv > 4) b += 8 + (size_t)nwv * l.nmax * 4;  // per-wave scratch of the wide forms (S4a keys, S5-init neighbour lists)
   {  // the threading DP re-uses the region: tuple-code map (u16) + one marginal table (u64 + u32)
     size_t codes = 1, marg = 1;
