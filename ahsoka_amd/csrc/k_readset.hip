@@ -653,7 +653,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, const
   unsigned int* firsts = tba + PW;
   unsigned int* lasts = firsts + PW;
   unsigned int* posm = lasts + PW;
-  unsigned int* keys = posm + PW;          // [G]
+  unsigned int* keys = (unsigned int*)(((size_t)(posm + PW) + 15) & ~(size_t)15);  // [G], 16-byte aligned
   unsigned int* srt = keys + Gs;           // [G]
   unsigned short* kname = (unsigned short*)(srt + Gs);  // [G]
   unsigned short* insname = kname + Gs;                 // [G]
@@ -952,7 +952,12 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, const
   for (int i = tid; i < n; i += kBlock) {
     unsigned int ki = keys[i];
     int rank = 0;
-    for (int j = 0; j < n; j++) rank += (keys[j] < ki) ? 1 : 0;
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {  // (keys is 16-byte aligned: four keys per LDS read, all lanes the same address)
+      const uint4 k4 = *reinterpret_cast<const uint4*>(keys + j);
+      rank += (k4.x < ki ? 1 : 0) + (k4.y < ki ? 1 : 0) + (k4.z < ki ? 1 : 0) + (k4.w < ki ? 1 : 0);
+    }
+    for (; j < n; j++) rank += (keys[j] < ki) ? 1 : 0;
     srt[rank] = ((ki >> 20) << 16) | (unsigned)rank;
     insname[rank] = kname[i];
     insfirst[rank] = kfirst[i];
@@ -1101,7 +1106,7 @@ size_t readset_lds2_bytes(const ReadsetLds2& l) {
   b += (size_t)((l.maxB + 2) & ~1) * 2 * 2;   // cidx padding, ahead
   b += (size_t)((l.maxSA + 15) & ~15);        // adup
   b += (size_t)((l.maxR + 2) & ~1) * 4;       // roff
-  b += (size_t)4 * ((l.maxB + 32) >> 5) * 4;  // tba, firsts, lasts, posm
+  b += (size_t)4 * ((l.maxB + 32) >> 5) * 4 + 16;  // tba, firsts, lasts, posm (+ the alignment of keys)
   b += (size_t)l.maxG * 4 * 2;                // keys, srt
   b += (size_t)l.maxG * 2 * 4;                // kname, insname, kfirst, insfirst
   b += (size_t)(l.maxB + 2) * 2;              // cidx
