@@ -722,11 +722,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
   unsigned long long* bestF = smem;               // [nmax]  (S4: per-wave key buffers; S6: histograms)
   unsigned long long* bestP = bestF + nmax;       // [nmax]
   unsigned short* cl = (unsigned short*)(bestP + nmax);  // [nmax] clique id, later cluster id
-  unsigned short* listA = cl + nmax;
-  unsigned short* listB = listA + nmax;
-  unsigned short* listFa = listB + nmax;
-  unsigned short* listFb = listFa + nmax;
-  unsigned short* rowbuf = listFb + nmax;                 // [4][nmax] as u16 = the first 2*nmax entries of the candidate-edge list (absent if !lds.items_lds)
+  // the member lists of the four roles of an iteration share ONE pool (they are disjoint sets of reads: at most n entries;
+  // every list starts on a 16-byte boundary for the 8- and 16-byte reads of the triangle loops).  As four arrays of nmax
+  // entries they were 8 B of LDS per read -- the 6 B saved pay for the live-word summary and keep the staged weight row
+  // (config 3) or a fourth workgroup per CU (config 4).
+  unsigned short* lpool = cl + nmax;                      // [nmax + 32]
+  unsigned short* rowbuf = lpool + nmax + 32;             // [4][nmax] as u16 = the first 2*nmax entries of the candidate-edge list (absent if !lds.items_lds)
   unsigned short* dlist = rowbuf + (lds.items_lds ? 4 * (size_t)nmax : 0);  // [nmax] rows whose maximum must be rescanned
   unsigned int* multiw = (unsigned int*)(dlist + nmax);   // [nmax/32] bit per read: its clique has > 1 member
   // RW = words of a bitmap row the class can have, 32 (n <= 2048) or 64: sizes the per-word role tables
@@ -734,6 +735,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
   static_assert(RW >= NWV * 8 && (RW == 32 || RW == 64 || RW == 128), "role tables");
   unsigned long long* rmask = (unsigned long long*)(multiw + ((nmax + 31) / 32 + 1) / 2 * 2);  // [4][RW] role masks per 64-column word
   unsigned long long* rolenz = rmask + 4 * RW;             // [4][RW] OR of the members' nz-rows
+  unsigned short* s_pref = (unsigned short*)rolenz;         // [4][64] word prefixes of the member lists: P2 only, before rolenz is written
+                                                            // (as a static array it was the 512 B that cost config 3 an LDS extra)
   unsigned char* role = (unsigned char*)(rolenz + 4 * RW);  // [nmax]
   int* wrow = (int*)(role + nmax);                         // [nmax] weights of a single read's row (see "staged row")
   // per-wave scratch of S4a (key buffer, u32) and S5 init (neighbour list, u16): the four-wave form
@@ -742,7 +745,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
   unsigned short* lwm = (unsigned short*)(wrow + (lds.stage_row ? nmax : 0));  // [nmax] live-word summary of every row (see lwm_words)
   unsigned int* wscr = NWV > 4 ? (unsigned int*)(((size_t)(lwm + nmax) + 7) & ~(size_t)7) : nullptr;  // [NWV][nmax]
   __shared__ int s_chain, s_cnt[4], s_nd, s_items, s_nh, s_nslow;
-  __shared__ unsigned short s_pref[4][64];
 #ifdef AHK_TIMING
   __shared__ int s_chg;
 #endif
@@ -942,8 +944,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
       // induced costs of a narrow (IC32) chain are < 2^32 and sums of non-negative terms: 32-bit
       // unsigned accumulators are exact there
       using AccT = typename std::conditional<IC32, unsigned int, long long>::type;
-      unsigned short* nbr = NWV > 4 ? (unsigned short*)(wscr + (size_t)wv * nmax)
-                                    : listA + (size_t)wv * nmax;   // union of the group's neighbours, ascending (the role lists are free here)
+      // nbr: union of the group's neighbours, ascending -- per-wave scratch: the wide forms have their own LDS region, the
+      // four-wave form takes the candidate-edge list's LDS part (free here) or, in a class that gave that up for a workgroup
+      // per CU, this slot's overflow region in HBM (a few dozen L2-resident lines per wave)
+      auto init_rows = [&](unsigned short* nbr) __attribute__((always_inline)) {
       for (int a0 = wv * kInitRows; a0 < n; a0 += NWV * kInitRows) {
         const int R = n - a0 < kInitRows ? n - a0 : kInitRows;
         int deg = 0, dhi = 0;
@@ -973,6 +977,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
 #pragma unroll
         for (int r = 0; r < kInitRows; r++)
           if (r < R && lane == 0) lwm[a0 + r] = (unsigned short)lw0[r];
+        __threadfence_block();  // (the list is handed from lane to lane of this wave, possibly through global memory)
         // lanes = the union's members b > a0 (the tail of the ascending list): a pair (a_r, b) of the
         // group is this wave's iff b > a_r and W[a_r][b] != 0.  The rows' own weights W[a_r][w] are
         // wave-uniform: 64 of them per row come with ONE load (lane = list index) and are handed out
@@ -1033,6 +1038,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           }
         }
       }
+      };
+      if (NWV > 4) init_rows((unsigned short*)(wscr + (size_t)wv * nmax));
+      else if (lds.items_lds) init_rows(rowbuf + (size_t)wv * nmax);
+      else init_rows((unsigned short*)items_glb + (size_t)wv * ws.nmax);
     }
     for (int u = tid; u < (n + 31) / 32; u += kThreads) multiw[u] = 0;
     if (tid < 4) s_cnt[tid] = 0;
@@ -1372,22 +1381,27 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         const unsigned long long mw = lane < nw ? rmask[wv * RW + lane] : 0ull;
         const int pc = __popcll(mw);
         const int incl = wave_scan_i(pc);
-        s_pref[wv][lane] = (unsigned short)(incl - pc);
+        s_pref[wv * 64 + lane] = (unsigned short)(incl - pc);
         if (lane == 63) s_cnt[wv] = incl;
-      }
-      __syncthreads();
-      for (int z = tid; z < n; z += kThreads) {
-        const int r = role[z];
-        if (r == ROLE_NONE) continue;
-        const int k = z >> 6;
-        const int slot = (int)s_pref[r - 1][k] + __popcll(rmask[(r - 1) * RW + k] & ((1ull << (z & 63)) - 1ull));
-        unsigned short* Lz = r == ROLE_A ? listA : r == ROLE_B ? listB : r == ROLE_FA ? listFa : listFb;
-        Lz[slot] = (unsigned short)z;
       }
       __syncthreads();
       const int nA = __builtin_amdgcn_readfirstlane(s_cnt[0]), nB = __builtin_amdgcn_readfirstlane(s_cnt[1]);
       const int nFa = __builtin_amdgcn_readfirstlane(s_cnt[2]), nFb = __builtin_amdgcn_readfirstlane(s_cnt[3]);
       const int nT = nA + nB + nFa + nFb;
+      // the four lists, one behind the other in the pool
+      unsigned short* const listA = lpool;
+      unsigned short* const listB = listA + ((nA + 7) & ~7);
+      unsigned short* const listFa = listB + ((nB + 7) & ~7);
+      unsigned short* const listFb = listFa + ((nFa + 7) & ~7);
+      for (int z = tid; z < n; z += kThreads) {
+        const int r = role[z];
+        if (r == ROLE_NONE) continue;
+        const int k = z >> 6;
+        const int slot = (int)s_pref[(r - 1) * 64 + k] + __popcll(rmask[(r - 1) * RW + k] & ((1ull << (z & 63)) - 1ull));
+        unsigned short* Lz = r == ROLE_A ? listA : r == ROLE_B ? listB : r == ROLE_FA ? listFa : listFb;
+        Lz[slot] = (unsigned short)z;
+      }
+      __syncthreads();
       // Edges priced from the staged row (the far end b is not rewritten itself, the row's only member
       // list is {rs}): roles whose rows qualify
       unsigned int ldsrole = 0u;
@@ -2586,7 +2600,7 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   const int rw0 = l.nmax > 2048 ? 64 : 32;
   const int rw = rw0 > nwv * 8 ? rw0 : nwv * 8;
   size_t b = (size_t)l.nmax * 8 * 2;       // bestF, bestP
-  b += (size_t)l.nmax * 2 * 5;             // cl + 4 lists
+  b += (size_t)l.nmax * 2 * 2 + 64;        // cl + the pool of the four member lists
   b += (size_t)l.nmax * 2 * (l.items_lds ? 5 : 1);  // rowbuf[4] (the LDS part of the candidate-edge list), dlist
   b += (size_t)(((l.nmax + 31) / 32 + 1) / 2 * 2) * 4;  // multiw (padded to 8 bytes)
   b += (size_t)2 * 4 * rw * 8;             // rmask, rolenz (and the per-wave pending lists that re-use them)
