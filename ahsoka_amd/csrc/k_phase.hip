@@ -743,7 +743,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
   // re-uses bestF/bestP and the role lists, which hold exactly four such buffers; the wide forms
   // have a region of their own (one workgroup or two per CU: the LDS is there)
   unsigned short* lwm = (unsigned short*)(wrow + (lds.stage_row ? nmax : 0));  // [nmax] live-word summary of every row (see lwm_words)
-  unsigned int* wscr = NWV > 4 ? (unsigned int*)(((size_t)(lwm + nmax) + 7) & ~(size_t)7) : nullptr;  // [NWV][nmax]
+  unsigned int* wscr = NWV > 4 ? (unsigned int*)(((size_t)(lwm + (AHK_LWM ? nmax : 0)) + 7) & ~(size_t)7) : nullptr;  // [NWV][nmax]
   __shared__ int s_chain, s_cnt[4], s_nd, s_items, s_nh, s_nslow;
 #ifdef AHK_TIMING
   __shared__ int s_chg;
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
         }
 #pragma unroll
         for (int r = 0; r < kInitRows; r++)
-          if (r < R && lane == 0) lwm[a0 + r] = (unsigned short)lw0[r];
+          if (AHK_LWM && r < R && lane == 0) lwm[a0 + r] = (unsigned short)lw0[r];
         __threadfence_block();  // (the list is handed from lane to lane of this wave, possibly through global memory)
         // lanes = the union's members b > a0 (the tail of the ascending list): a pair (a_r, b) of the
         // group is this wave's iff b > a_r and W[a_r][b] != 0.  The rows' own weights W[a_r][w] are
@@ -1517,7 +1517,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
             const unsigned long long nzn = nzw | D;
             if (lvn != lvw) {
               LV_AT((unsigned)(x * nw + kw)) = lvn;
-              if (glog == 0 && lvn == 0ull) lwm_clear(lwm, x, kw);
+              if (AHK_LWM && glog == 0 && lvn == 0ull) lwm_clear(lwm, x, kw);
             }
             if (nzn != nzw) NZ_AT((unsigned)(x * nw + kw)) = nzn;
             const int xw = x >> 6;
@@ -2606,7 +2606,7 @@ size_t phase_lds_bytes(const PhaseLds& l) {
   b += (size_t)2 * 4 * rw * 8;             // rmask, rolenz (and the per-wave pending lists that re-use them)
   b += (size_t)l.nmax;                     // role
   if (l.stage_row) b += (size_t)l.nmax * 4;  // wrow
-  b += (size_t)l.nmax * 2;                 // lwm
+  if (AHK_LWM) b += (size_t)l.nmax * 2;    // lwm
   if (nwv > 4) b += 8 + (size_t)nwv * l.nmax * 4;  // per-wave scratch of the wide forms (S4a keys, S5-init neighbour lists)
   {  // the threading DP re-uses the region: tuple-code map (u16) + one marginal table (u64 + u32)
     size_t codes = 1, marg = 1;
