@@ -115,7 +115,7 @@ ABI_SYMBOLS = [
     "ahsoka_batch_free", "ahsoka_batch_result_device", "ahsoka_batch_kernel_times", "ahsoka_batch_bytes", "ahsoka_render_chain",
     "ahsoka_ingest", "ahsoka_ingest_dump", "ahsoka_batch_host_free", "ahsoka_synth_batch", "ahsoka_synth_select", "ahsoka_synth_shapes", "ahsoka_synth_write_text", "ahsoka_synth_truth",
     "ahsoka_test_introsort_u32", "ahsoka_test_introsort_par_u32", "ahsoka_test_detlog",
-    "ahsoka_test_multi_plan", "ahsoka_kernel_revision",
+    "ahsoka_test_multi_plan", "ahsoka_kernel_revision", "ahsoka_batch_class_info",
 ]
 
 _lib = None
@@ -148,6 +148,7 @@ def lib() -> C.CDLL:
     L.ahsoka_batch_free.argtypes = [C.c_void_p]
     L.ahsoka_batch_free.restype = None
     L.ahsoka_batch_result_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.ahsoka_batch_class_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32]
     L.ahsoka_batch_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_char_p)),
                                             C.POINTER(C.POINTER(C.c_float))]
     L.ahsoka_batch_bytes.argtypes = [C.POINTER(CChainBatch), C.c_int32, C.POINTER(C.c_int64)]
@@ -483,6 +484,14 @@ class DeviceBatch:
         ms = C.POINTER(C.c_float)()
         _check(lib().ahsoka_batch_kernel_times(self._h, C.byref(n), C.byref(names), C.byref(ms)), "kernel_times")
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+    def class_info(self) -> List[Dict[str, int]]:
+        """size classes of the last phase() call: nmax, chains, slots, waves, workgroups per CU, LDS bytes, extras"""
+        n = C.c_int32()
+        buf = (C.c_int32 * (8 * 16))()
+        _check(lib().ahsoka_batch_class_info(self._h, C.byref(n), buf, 8 * 16), "ahsoka_batch_class_info")
+        keys = ("nmax", "chains", "slots", "waves", "workgroups_per_cu", "lds_bytes", "items_lds", "stage_row")
+        return [dict(zip(keys, buf[8 * k:8 * k + 8])) for k in range(min(n.value, 16))]
 
     def result_device(self):
         """(device pointer, number of int32) of the packed result record block

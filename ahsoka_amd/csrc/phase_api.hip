@@ -77,6 +77,7 @@ void parallel_ranges(long long n, long long grain, F fn) {
 // chains do not dictate the footprint (and LDS occupancy) of the many small ones.
 struct PhaseClass {
   int nmax = 0, slots = 0, count = 0, Pmax = 1;
+  int per_cu = 0;  // workgroups of k_phase per CU the class was sized for
   PhaseLds pl{};
   SlotWorkspace ws{};
   int* queue = nullptr;  // device: this class's chains, most expensive first
@@ -718,6 +719,7 @@ static int build_classes(ahsoka_device_batch* h) {
     std::fprintf(stderr, "ahsoka: class nmax=%d chains=%d waves=%d workgroups/CU=%d lds=%zu B items_lds=%d stage_row=%d\n", pc.nmax, pc.count,
                  pc.pl.nwv, per_cu, phase_lds_bytes(pc.pl), pc.pl.items_lds, pc.pl.stage_row);
 #endif
+    pc.per_cu = per_cu;
     pc.slots = std::max(1, std::min(pc.count, h->n_cu * per_cu));
     if (h->prm.max_slots > 0) pc.slots = std::min(pc.slots, h->prm.max_slots);
     h->classes.push_back(pc);
@@ -854,6 +856,25 @@ extern "C" int ahsoka_batch_result_device(ahsoka_device_batch* h, void** dev_ptr
   HIP_TRY(hipStreamSynchronize(h->stream));
   *dev_ptr = h->packed;
   *n_int32 = (int64_t)total;
+  return AHSOKA_OK;
+}
+
+// (see the header: how the size classes of the last ahsoka_phase_device call were laid out)
+extern "C" int ahsoka_batch_class_info(ahsoka_device_batch* h, int32_t* n_classes, int32_t* out, int32_t cap) {
+  if (!h || !n_classes) return AHSOKA_E_ARG;
+  *n_classes = (int32_t)h->classes.size();
+  for (size_t k = 0; k < h->classes.size() && out && (int64_t)(k + 1) * 8 <= cap; k++) {
+    const PhaseClass& pc = h->classes[k];
+    int32_t* o = out + 8 * k;
+    o[0] = pc.nmax;
+    o[1] = pc.count;
+    o[2] = pc.slots;
+    o[3] = pc.pl.nwv;
+    o[4] = pc.per_cu;
+    o[5] = (int32_t)phase_lds_bytes(pc.pl);
+    o[6] = pc.pl.items_lds;
+    o[7] = pc.pl.stage_row;
+  }
   return AHSOKA_OK;
 }
 

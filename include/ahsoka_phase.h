@@ -223,6 +223,16 @@ void ahsoka_batch_free(ahsoka_device_batch* handle);
 int ahsoka_batch_kernel_times(ahsoka_device_batch* handle, int32_t* n, const char*** names,
                               const float** ms);
 /*
+ * How the last ahsoka_phase_device call laid out its size classes (chains are binned by the size of
+ * their final readset; every class has its own pool of slots, queue and launch of the
+ * cluster-editing kernel).  out: 8 int32 per class -- largest readset the class holds, chains,
+ * slots, wavefronts per workgroup, workgroups per CU, bytes of LDS per workgroup, and whether the
+ * workgroup keeps the first part of an iteration's candidate-edge list (8 B per read) and the staged
+ * weight row (4 B per read) in LDS.  The chains in flight are what the 160 KB of LDS per CU allow:
+ * this is the view of that budget (tests pin it for the BASELINE shapes).  cap = int32 capacity of out.
+ */
+int ahsoka_batch_class_info(ahsoka_device_batch* handle, int32_t* n_classes, int32_t* out, int32_t cap);
+/*
  * The result of the last ahsoka_phase_device call as ONE device-resident int32
  * record block with a layout that depends only on the batch shape, so that ranks
  * can exchange results with a single fixed-size collective (RCCL gather) without

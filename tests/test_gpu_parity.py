@@ -351,7 +351,12 @@ def test_c4_full_size_properties():
     g = dev.download()
     dev.phase()
     g2 = dev.download()
+    classes = dev.class_info()
     dev.free()
+    # the LDS budget of its size class: four workgroups per CU WITH the staged weight row --
+    # two bytes of LDS per read too many cost it the fourth workgroup (-9 %) for half of round 3 without any test noticing
+    assert len(classes) == 1 and classes[0]["waves"] == 4, classes
+    assert classes[0]["workgroups_per_cu"] == 4 and classes[0]["stage_row"] == 1, classes
     np.testing.assert_array_equal(g.hap_allele, g2.hap_allele)
     np.testing.assert_array_equal(g.hap_cluster, g2.hap_cluster)
     np.testing.assert_array_equal(g.n_iterations, g2.n_iterations)
@@ -405,7 +410,12 @@ def test_c3_full_size_properties():
     g = dev.download()
     dev.phase()                      # idempotence: the same call gives the same bits
     g2 = dev.download()
+    classes = dev.class_info()
     dev.free()
+    # the LDS budget of the bench workload's size class: five workgroups per CU with BOTH extras (the LDS part of the
+    # candidate-edge list and the staged weight row); 512 B of LDS too many had silently cost it the staged row (-2.4 %)
+    assert len(classes) == 1 and classes[0]["waves"] == 4 and classes[0]["slots"] == 1280, classes
+    assert classes[0]["workgroups_per_cu"] == 5 and classes[0]["items_lds"] == 1 and classes[0]["stage_row"] == 1, classes
     np.testing.assert_array_equal(g.hap_allele, g2.hap_allele)
     np.testing.assert_array_equal(g.n_iterations, g2.n_iterations)
     assert (g.status == capi.ST_PHASED).all()
