@@ -511,6 +511,7 @@ struct MatchCtx {
   const unsigned long long* minner; // [SA][wordsN] ... without its first and last node
   const unsigned short* ahead;      // [B+1] first allele of every bubble (chain-local allele index)
   const unsigned char* adup;        // [SA] path repeats a node: exact multiset test on the node lists
+  const unsigned char* bwin;        // [B] first | last << 4 of the bitset words the bubble's allele paths touch (wordsN <= 4)
   int R, wordsN;
   const DeviceBatch* db;
   long long a_base;       // global index of the chain's first allele
@@ -612,19 +613,37 @@ __device__ __forceinline__ int merged_match(const MatchCtx& mc, int k, const Nam
 // the common shape only: every name of the group has exactly one alignment, no allele path of
 // the chain repeats a node, at most 256 nodes (bitsets in registers); otherwise the per-name
 // code runs.  res[j] = first matching allele of name j at bubble k or -1.
+// nab[j] = the COMPLEMENT of name j's node bitset (an allele matches when mask & ~bits == 0).  The nodes of
+// one bubble are neighbours in the chain-local numbering, so all of its allele paths touch one bitset word
+// (two where the bubble straddles a 64-node boundary): bwin[k] names the words, the test of an allele is
+// then one 64-bit AND per name instead of wordsN of them (the match passes are bound by these instructions).
 template <bool PARTIAL>
-__device__ __forceinline__ void match4(const MatchCtx& mc, const AlnBits (&ab)[4], int k, int (&res)[4]) {
+__device__ __forceinline__ void match4(const MatchCtx& mc, const unsigned long long (&nab)[4][4], int k, int (&res)[4]) {
   const unsigned long long* mk = PARTIAL ? mc.minner : mc.mfull;
   const int a0 = mc.ahead[k], a1 = mc.ahead[k + 1];
+  const int win = __builtin_amdgcn_readfirstlane((int)mc.bwin[k]);
+  const int wlo = win & 15, whi = win >> 4;
 #pragma unroll
   for (int j = 0; j < 4; j++) res[j] = -1;
+  if (wlo >= whi) {  // one word (or no node at all): uniform
+    unsigned long long s[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) s[j] = wlo == 0 ? nab[j][0] : wlo == 1 ? nab[j][1] : wlo == 2 ? nab[j][2] : nab[j][3];
+    for (int a = a0; a < a1; a++) {
+      const unsigned long long mw = mk[(size_t)a * mc.wordsN + wlo];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (res[j] < 0 && (mw & s[j]) == 0ull) res[j] = a - a0;
+    }
+    return;
+  }
   for (int a = a0; a < a1; a++) {
     unsigned long long mw[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) mw[w] = w < mc.wordsN ? mk[(size_t)a * mc.wordsN + w] : 0ull;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const unsigned long long miss = (mw[0] & ~ab[j].w[0]) | (mw[1] & ~ab[j].w[1]) | (mw[2] & ~ab[j].w[2]) | (mw[3] & ~ab[j].w[3]);
+      const unsigned long long miss = (mw[0] & nab[j][0]) | (mw[1] & nab[j][1]) | (mw[2] & nab[j][2]) | (mw[3] & nab[j][3]);
       if (res[j] < 0 && miss == 0ull) res[j] = a - a0;
     }
   }
@@ -653,7 +672,9 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, const
   unsigned int* firsts = tba + PW;
   unsigned int* lasts = firsts + PW;
   unsigned int* posm = lasts + PW;
-  unsigned int* keys = (unsigned int*)(((size_t)(posm + PW) + 15) & ~(size_t)15);  // [G], 16-byte aligned
+  // [G], 16-byte aligned (by element arithmetic: a round trip through an integer would turn every array behind it into a
+  // generic pointer, i.e. flat_* instead of ds_* instructions -- 110 of them in this kernel when it was written that way)
+  unsigned int* keys = posm + PW + ((4 - ((int)((posm + PW) - (unsigned int*)smem) & 3)) & 3);
   unsigned int* srt = keys + Gs;           // [G]
   unsigned short* kname = (unsigned short*)(srt + Gs);  // [G]
   unsigned short* insname = kname + Gs;                 // [G]
@@ -662,6 +683,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, const
   unsigned short* cidx = insfirst + Gs;                 // [B+1]
   unsigned short* ahead = cidx + ((Bs + 2) & ~1);       // [B+1]
   unsigned char* adup = (unsigned char*)(ahead + ((Bs + 2) & ~1));  // [SA]
+  unsigned char* bwin = adup + ((SA + 15) & ~15);                    // [B] word window of the bubble's allele paths
   __shared__ int s_maxpos, s_any, s_n, s_P, s_anydup;
 
   for (int w = tid; w < PW; w += kBlock) { tba[w] = 0; firsts[w] = 0; lasts[w] = 0; posm[w] = 0; }
@@ -709,6 +731,20 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, const
     }
   }
   __syncthreads();
+#ifdef AHK_RS_TIMING
+  rs_t[6] = (long long)clock64() - rs_last;  // phase A: arrays zeroed, offsets and allele masks in LDS
+#endif
+  // the bitset words every bubble's allele paths touch (see match4)
+  for (int k = tid; k < B; k += kBlock) {
+    int lo = 15, hi = 0;
+    for (int a = ahead[k]; a < ahead[k + 1]; a++)
+      for (int w = 0; w < wordsN && w < 15; w++)
+        if (mfull[(size_t)a * wordsN + w] != 0ull) {
+          lo = w < lo ? w : lo;
+          hi = w > hi ? w : hi;
+        }
+    bwin[k] = (unsigned char)(lo > hi ? 0 : (lo | (hi << 4)));
+  }
   {
     // each wave streams one contiguous quarter of the chain's entries, 4 x 64 per trip (the four
     // loads are in flight together); the alignment of an entry is found by walking forward
@@ -751,6 +787,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, const
   mc.minner = minner;
   mc.ahead = ahead;
   mc.adup = adup;
+  mc.bwin = bwin;
   mc.R = R;
   mc.wordsN = wordsN;
   mc.db = &db;
@@ -792,10 +829,14 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, const
 #pragma unroll
     for (int j = 0; j < 4; j++) { nvar[j] = 0; first[j] = B; last[j] = -1; mapq[j] = -1; }
     if (quad) {
-      AlnBits ab[4];
+      unsigned long long ab[4][4];  // complemented bitsets
       int mq[4];  // (a single alignment per name: the creator is known up front)
 #pragma unroll
-      for (int j = 0; j < 4; j++) { ab[j] = na[j].ab; mq[j] = db.read_mapq[m.r0 + na[j].r]; }
+      for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) ab[j][w] = ~na[j].ab.w[w];
+        mq[j] = db.read_mapq[m.r0 + na[j].r];
+      }
       for (int kk = 0; kk < B; kk++) {
         const int k = s1l[kk];
         int res[4];
@@ -878,11 +919,16 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, const
 #pragma unroll
     for (int j = 0; j < 4; j++) { nvar[j] = 0; first[j] = -1; afirst[j] = 0; rcre[j] = 0; mapq[j] = -1; cv0[j] = 0ull; cv1[j] = 0ull; }
     if (quad) {
-      AlnBits ab[4];
+      unsigned long long ab[4][4];  // complemented bitsets
       bool gt90[4];
       int mq[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) { ab[j] = na[j].ab; gt90[j] = (fl[na[j].r] & 1) != 0; mq[j] = db.read_mapq[m.r0 + na[j].r]; }
+      for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) ab[j][w] = ~na[j].ab.w[w];
+        gt90[j] = (fl[na[j].r] & 1) != 0;
+        mq[j] = db.read_mapq[m.r0 + na[j].r];
+      }
       for (int k = 0; k < B; k++) {
         if (!tba_test(tba, k)) continue;
         int res[4];
@@ -1002,12 +1048,13 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, const
       quad = quad && na[j].r >= 0;
     }
     if (quad) {
-      AlnBits ab[4];
+      unsigned long long ab[4][4];  // complemented bitsets
       bool gt90[4];
       unsigned long long cw[4], p0[4], p1[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        ab[j] = na[j].ab;
+#pragma unroll
+        for (int w = 0; w < 4; w++) ab[j][w] = ~na[j].ab.w[w];
         gt90[j] = (fl[na[j].r] & 1) != 0;
         cw[j] = p0[j] = p1[j] = 0ull;
       }
@@ -1090,8 +1137,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_readset_lds(DeviceBatch db, const
   RS_T();  // 5: phase E
 #ifdef AHK_RS_TIMING
   if (tid == 0 && blockIdx.x == 0)
-    printf("k_readset_lds chain %d R=%d n=%d cycles: A=%lld B=%lld C=%lld rank=%lld sort=%lld E=%lld\n", c, R, n, rs_t[0], rs_t[1], rs_t[2],
-           rs_t[3], rs_t[4], rs_t[5]);
+    printf("k_readset_lds chain %d R=%d n=%d cycles: A=%lld (masks and offsets staged after %lld) B=%lld C=%lld rank=%lld sort=%lld E=%lld\n", c, R, n, rs_t[0],
+           rs_t[6], rs_t[1], rs_t[2], rs_t[3], rs_t[4], rs_t[5]);
 #endif
   if (tid == 0) {
     db.status[c] = AHSOKA_ST_PHASED;
@@ -1105,6 +1152,7 @@ size_t readset_lds2_bytes(const ReadsetLds2& l) {
   b += (size_t)l.maxMaskWords * 8 * 2;        // allele masks, full and inner
   b += (size_t)((l.maxB + 2) & ~1) * 2 * 2;   // cidx padding, ahead
   b += (size_t)((l.maxSA + 15) & ~15);        // adup
+  b += (size_t)((l.maxB + 15) & ~15);         // bwin
   b += (size_t)((l.maxR + 2) & ~1) * 4;       // roff
   b += (size_t)4 * ((l.maxB + 32) >> 5) * 4 + 16;  // tba, firsts, lasts, posm (+ the alignment of keys)
   b += (size_t)l.maxG * 4 * 2;                // keys, srt
