@@ -755,6 +755,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
   bool ft_first = blockIdx.x == 0;
 #endif
   __shared__ int s_asc[4][8];
+#if AHK_LWM
+  __shared__ int s_clr[2];  // single-read separation: word + 1 of row eu / ev whose last live edge has just died (0: none)
+#endif
   __shared__ int s_back;
 
   int* Wm = ws.W + (size_t)blockIdx.x * ws.nmax * ws.nmax;
@@ -1215,7 +1218,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
               lvn &= ~(1ull << (w & 63));
               if (sub == 0) {
                 LV_AT((unsigned)(x * nw + lane)) = lvn;
-                if (glog == 0 && lvn == 0ull) lwm_clear(lwm, x, lane);
+                // (the summary bit of a word that has just become empty is cleared BEHIND the barrier below: the waves
+                // of a row split its words by rank in the summary, and a wave that read the summary after the bit
+                // had gone would take a word its partner also takes -- seen once in 10 000 chains as a different
+                // iteration count between two runs)
+                s_clr[half] = (glog == 0 && lvn == 0ull) ? lane + 1 : 0;
               }
             }
           }
@@ -1275,7 +1282,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
 #if AHK_LWM
         if (first && lane == (w >> 6)) {  // (a row whose summary was empty: only the dying edge's word is rewritten)
           lvn &= ~(1ull << (w & 63));
-          if (sub == 0) LV_AT((unsigned)(x * nw + lane)) = lvn;
+          if (sub == 0) {
+            LV_AT((unsigned)(x * nw + lane)) = lvn;
+            s_clr[half] = 0;
+          }
         }
 #endif
         AHK_F(5);
@@ -1314,6 +1324,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? AHK_WAVES_PER_SIMD : 4) void k
           }
           bestF[xr] = a1;
           bestP[xr] = b1;
+#if AHK_LWM
+          if (s_clr[tid] != 0) lwm_clear(lwm, xr, s_clr[tid] - 1);  // (half 0 = row eu, half 1 = row ev)
+#endif
           WM_AT((unsigned)(xr * n + (tid ? eu : ev))) = W_FORB;  // every wave has read the old weight by now
         }
         __syncthreads();

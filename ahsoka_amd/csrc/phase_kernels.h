@@ -7,7 +7,7 @@
 // that can move their HBM traffic or time: a committed counter summary (profiles/*_pmc_hbm.json)
 // carries the tag it was taken with, and bench.py reports `roofline.traffic` only from a summary
 // of the SAME revision (never a counter of one kernel version next to a time of another).
-#define AHK_KERNEL_REV "r03.7"
+#define AHK_KERNEL_REV "r03.8"
 
 namespace ahk {
 
